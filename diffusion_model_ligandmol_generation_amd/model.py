@@ -1,0 +1,101 @@
+"""Drop-in score network: the reference's constructor / forward signature over the HIP library.
+
+Mirrors ResearchAccurateDiffusionModel of model1.py:564-764.  The module tree only holds
+parameters (see modules.py); ``forward`` packs the ragged batch into the CSR layout and
+runs the whole network through the C-ABI library (csrc/), on the current HIP stream.
+There is no CPU or eager-PyTorch fallback: on a machine without the library or without
+a GPU, ``forward`` raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .modules import (EDMPreconditioning, E3EquivariantMessagePassing, GraphDiTLayer,
+                      MolDiffConsistencyModule, PILOTMultiObjectiveGuidance)
+
+
+def cosine_beta_schedule(timesteps):
+    """Host-side, one-off: model1.py:674-684."""
+    s = 0.008
+    x = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float32)
+    ac = torch.cos(((x / timesteps) + s) / (1 + s) * math.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    return torch.clamp(1 - (ac[1:] / ac[:-1]), 0.0001, 0.02)
+
+
+class ResearchAccurateDiffusionModel(nn.Module):
+    """Same constructor arguments, attributes, buffers and state_dict keys as
+    model1.py:574-665.  hidden_dim is fixed at 256, num_heads at 8, atom_feature_dim at
+    119 and three + three layers by the kernels' tiling; other values raise."""
+
+    def __init__(self, atom_feature_dim=119, edge_feature_dim=5, hidden_dim=256, num_layers=6,
+                 num_heads=8, timesteps=1000, property_dim=15, max_atoms=100,
+                 sigma_min=0.002, sigma_max=80.0, sigma_data=0.5):
+        super().__init__()
+        if hidden_dim != 256 or num_heads != 8 or atom_feature_dim != 119 or property_dim != 15:
+            raise ValueError("the HIP kernels are built for hidden_dim=256, num_heads=8, "
+                             "atom_feature_dim=119, property_dim=15")
+        if max_atoms > 128:
+            raise ValueError("max_atoms above 128 is not supported by the attention kernel")
+        self.atom_feature_dim = atom_feature_dim
+        self.hidden_dim = hidden_dim
+        self.timesteps = timesteps
+        self.max_atoms = max_atoms
+        self.num_heads = num_heads
+        self.property_dim = property_dim
+
+        self.edm_preconditioning = EDMPreconditioning(sigma_min, sigma_max, sigma_data)
+        self.atom_embedding = nn.Sequential(nn.Linear(atom_feature_dim, hidden_dim), nn.LayerNorm(hidden_dim), nn.GELU())
+        self.pos_embedding = nn.Sequential(nn.Linear(3, hidden_dim), nn.LayerNorm(hidden_dim), nn.GELU())
+        self.time_mlp = nn.Sequential(nn.Linear(hidden_dim, hidden_dim * 2), nn.GELU(),
+                                      nn.Linear(hidden_dim * 2, hidden_dim))
+        self.property_guidance = PILOTMultiObjectiveGuidance(property_dim, hidden_dim)
+        self.equivariant_layers = nn.ModuleList(
+            [E3EquivariantMessagePassing(hidden_dim) for _ in range(num_layers // 2)])
+        self.dit_layers = nn.ModuleList([GraphDiTLayer(hidden_dim, num_heads) for _ in range(num_layers // 2)])
+        self.moldiff_consistency = MolDiffConsistencyModule(hidden_dim, max_atoms)
+
+        def head(out):
+            return nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.GELU(), nn.LayerNorm(hidden_dim),
+                                 nn.Linear(hidden_dim, out))
+
+        self.atom_output = head(atom_feature_dim)
+        self.pos_output = head(3)
+        self.property_output = head(property_dim)
+
+        betas = cosine_beta_schedule(timesteps)
+        self.register_buffer("betas", betas)
+        alphas = 1.0 - betas
+        self.register_buffer("alphas", alphas)
+        alphas_cumprod = torch.cumprod(alphas, dim=0)
+        self.register_buffer("alphas_cumprod", alphas_cumprod)
+        self.register_buffer("sqrt_alphas_cumprod", torch.sqrt(alphas_cumprod))
+        self.register_buffer("sqrt_one_minus_alphas_cumprod", torch.sqrt(1.0 - alphas_cumprod))
+        self._engine = None
+
+    # ------------------------------------------------------------------ engine plumbing
+    def engine(self):
+        """The per-model handle on the HIP library (weights table + workspaces)."""
+        from .engine import ScoreNetworkEngine
+        if self._engine is None or self._engine.stale(self):
+            self._engine = ScoreNetworkEngine(self)
+        return self._engine
+
+    def forward(self, data, t, properties=None, classifier_free_guidance=False):
+        """model1.py:699-755.  ``data`` is any object with .x [N,119], .pos [N,3],
+        .edge_index [2,E] int64 and .batch [N] int64 (sorted).  Returns
+        (atom_pred [N,119], pos_pred [N,3], prop_pred [B,15], consistency_outputs).
+
+        consistency_outputs is always None: the MolDiff consistency module only runs in
+        train mode in the reference (model1.py:750-753) and none of its outputs reaches
+        a loss with the data pipeline's batches (train.py:519, :543, :559, :583).
+        Errors raise instead of being turned into zero predictions (model1.py:757-764).
+        """
+        from .autograd import score_network_apply
+        atom_pred, pos_pred, prop_pred = score_network_apply(self, data, t, properties,
+                                                             classifier_free_guidance)
+        return atom_pred, pos_pred, prop_pred, None
+
+
+ResearchValidatedDiffusionModel = ResearchAccurateDiffusionModel  # model1.py:1035

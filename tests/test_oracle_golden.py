@@ -1,0 +1,129 @@
+"""CPU: the oracle restatement against fixtures produced by the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import golden, seed0_state_dict
+
+
+def test_template_connectivity_bit_exact():
+    f = golden("connectivity.npz")
+    ns = sorted(int(k.split("_")[1]) for k in f.files if k.startswith("edges_"))
+    assert 1 in ns and 128 in ns
+    for n in ns:
+        edges, feats = oracle.template_connectivity(n)
+        assert np.array_equal(np.asarray(edges, dtype=np.int64).reshape(-1, 2), f[f"edges_{n}"]), n
+        assert np.array_equal(np.asarray(feats, dtype=np.float32).reshape(-1, 5), f[f"feats_{n}"]), n
+        expect = 2 * (n - 1) if n <= 5 else (2 * n if n <= 15 else 2 * n + 4)
+        assert len(edges) == max(expect, 0)
+
+
+@pytest.mark.parametrize("T,suffix", [(1000, ""), (50, "_T50")])
+def test_schedule_bit_exact(T, suffix):
+    f = golden("schedule.npz")
+    s = oracle.cosine_schedule(T)
+    for k in ("betas", "alphas", "alphas_cumprod"):
+        assert np.array_equal(s[k].numpy(), f[k + suffix]), k
+    if T == 1000:
+        assert np.array_equal(s["sqrt_alphas_cumprod"].numpy(), f["sqrt_alphas_cumprod"])
+        assert abs(float(s["alphas_cumprod"][999]) - 0.0031948) < 1e-6
+
+
+@pytest.mark.parametrize("name,tkey,use_props,cfg", [
+    ("int_noprop", "t_int", False, False), ("flt_noprop", "t_flt", False, False),
+    ("int_prop", "t_int", True, False), ("int_cfgnull", "t_int", True, True)])
+@pytest.mark.parametrize("pad", [True, False])
+def test_forward_matches_reference(name, tkey, use_props, cfg, pad):
+    f = golden("forward.npz")
+    sd = seed0_state_dict()
+    x, pos, ei, b = (torch.from_numpy(f[k]) for k in ("x", "pos", "edge_index", "batch"))
+    props = torch.from_numpy(f["props"]) if use_props else None
+    with torch.no_grad():
+        a, p, r = oracle.score_network_forward(sd, x, pos, ei, b, torch.from_numpy(f[tkey]), props, cfg,
+                                               pad_to_max_atoms=pad)
+    for got, key in ((a, "atom"), (p, "pos"), (r, "prop")):
+        torch.testing.assert_close(got, torch.from_numpy(f[f"{name}_{key}"]), rtol=1e-5, atol=5e-6)
+
+
+def test_forward_big_molecules_matches_reference():
+    f = golden("forward.npz")
+    sd = seed0_state_dict(max_atoms=128)
+    with torch.no_grad():
+        a, p, r = oracle.score_network_forward(
+            sd, torch.from_numpy(f["big_x"]), torch.from_numpy(f["big_pos"]),
+            torch.from_numpy(f["big_edge_index"]), torch.from_numpy(f["big_batch"]),
+            torch.from_numpy(f["big_t"]), None, max_atoms=128, pad_to_max_atoms=False)
+    torch.testing.assert_close(a, torch.from_numpy(f["big_atom"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(p, torch.from_numpy(f["big_pos_pred"]), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(r, torch.from_numpy(f["big_prop"]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["noprop", "prop"])
+def test_loss_step_and_gradients_match_reference(tag):
+    f = golden("loss_step.npz")
+    base = seed0_state_dict()
+    from conftest import seed0_model
+    pnames = {n for n, _ in seed0_model().named_parameters()}
+    sd = {k: (v.requires_grad_(True) if k in pnames else v) for k, v in base.items()}
+    x, pos, ei, b = (torch.from_numpy(f[k]) for k in ("x", "pos", "edge_index", "batch"))
+    props = torch.from_numpy(f["props"]) if tag == "prop" else None
+    L, _ = oracle.loss_step(sd, x, pos, ei, b, torch.from_numpy(f[tag + "_u"]),
+                            torch.from_numpy(f[tag + "_noise"]), props,
+                            torch.from_numpy(f[tag + "_null_rand"]))
+    n_checked = 0
+    for k, v in L.items():
+        key = f"{tag}_loss_{k}"
+        if key in f.files:
+            assert abs(float(v.detach()) - float(f[key])) <= 1e-5 * max(1e-3, abs(float(f[key]))), k
+            n_checked += 1
+    assert n_checked >= 10
+    L["total_loss"].backward()
+    gsq = 0.0
+    for k, v in sd.items():
+        if v.grad is None:
+            assert f"{tag}_gradsum_{k}" not in f.files or float(f[f"{tag}_gradsum_{k}"][1]) == 0.0, k
+            continue
+        gsq += float((v.grad.double() ** 2).sum())
+        key = f"{tag}_grad_{k}"
+        if key in f.files:
+            ref = torch.from_numpy(f[key])
+            assert float((v.grad - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, k
+    assert abs(gsq ** 0.5 - float(f[tag + "_gradnorm"])) <= 1e-5 * float(f[tag + "_gradnorm"])
+
+
+@pytest.mark.parametrize("tag", ["ddpm_T50", "ddpm_T50_cfg", "ddim_T1000"])
+def test_sampler_trajectory_matches_reference(tag):
+    s = golden("sampler.npz")
+    T, n, ddim_steps, seed, wp = [int(v) for v in s[tag + "_meta"]]
+    sd = seed0_state_dict(timesteps=T)
+    sched = oracle.cosine_schedule(T)
+    torch.manual_seed(seed)
+    snaps = {}
+
+    def trace(t, x, p):
+        snaps[t] = (x.clone(), p.clone())
+
+    tp = torch.from_numpy(s[tag + "_props"]) if wp else None
+    noise = lambda shape: torch.randn(*shape)  # noqa: E731
+    with torch.no_grad():
+        if ddim_steps:
+            x, p = oracle.ddim_sample(sd, sched, n, noise, ddim_steps, tp, 2.0, 0.9, trace=trace)
+        else:
+            x, p = oracle.ddpm_sample(sd, sched, n, noise, tp, 2.0, 0.9, trace=trace)
+    for i, t in enumerate(s[tag + "_snap_t"]):
+        torch.testing.assert_close(snaps[int(t)][0], torch.from_numpy(s[tag + "_snap_x"][i]), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(snaps[int(t)][1], torch.from_numpy(s[tag + "_snap_pos"][i]), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(x, torch.from_numpy(s[tag + "_final_x"]), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(p, torch.from_numpy(s[tag + "_final_pos"]), rtol=1e-4, atol=1e-4)
+
+
+def test_pack_csr_small():
+    ei = np.array([[0, 1, 1, 2, 3, 0], [1, 0, 2, 1, 1, 3]])
+    batch = np.array([0, 0, 0, 1])
+    p = oracle.pack_csr(ei, batch)
+    assert p["mol_ptr"].tolist() == [0, 3, 4]
+    assert p["row_ptr"].tolist() == [0, 1, 4, 5, 6]
+    assert p["perm"].tolist() == [1, 0, 3, 4, 2, 5]
+    assert p["src"].tolist() == [1, 0, 2, 3, 1, 0]
+    assert p["dst"].tolist() == [0, 1, 1, 1, 2, 3]
