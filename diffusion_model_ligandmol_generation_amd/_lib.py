@@ -1,0 +1,91 @@
+"""ctypes binding of libligdiff.so (declared in include/ligdiff.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent the import
+of the hot path fails loudly.  Build it with ``python __graft_entry__.py`` (or
+``csrc/build.sh``); the .so sits next to this file.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libligdiff.so")
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+
+
+class Graph(C.Structure):
+    """struct ligdiff_graph"""
+    _fields_ = [("n_atoms", C.c_int64), ("n_edges", C.c_int64), ("n_mols", C.c_int32),
+                ("max_mol_atoms", C.c_int32), ("mol_ptr", C.c_void_p), ("atom_mol", C.c_void_p),
+                ("dst_ptr", C.c_void_p), ("src", C.c_void_p), ("dst", C.c_void_p), ("perm", C.c_void_p),
+                ("src_ptr", C.c_void_p), ("src_slot", C.c_void_p)]
+
+
+class StepArgs(C.Structure):
+    """struct ligdiff_step_args"""
+    _fields_ = [("x", C.c_void_p), ("pos", C.c_void_p), ("eps_x", C.c_void_p), ("eps_pos", C.c_void_p),
+                ("eps_x_uncond", C.c_void_p), ("eps_pos_uncond", C.c_void_p),
+                ("guidance_scale", C.c_float), ("temperature", C.c_float),
+                ("betas", C.c_void_p), ("alphas", C.c_void_p), ("alphas_cumprod", C.c_void_p),
+                ("t_index_dev", C.c_void_p), ("noise_x", C.c_void_p), ("noise_pos", C.c_void_p),
+                ("seed", C.c_uint64), ("atom_offset", C.c_int64), ("n_atoms", C.c_int64)]
+
+
+# name -> (restype, argtypes); every symbol include/ligdiff.h declares
+SIGNATURES = {
+    "ligdiff_version": (C.c_int, []),
+    "ligdiff_status_string": (C.c_char_p, [C.c_int]),
+    "ligdiff_weight_count": (C.c_int, []),
+    "ligdiff_weight_name": (C.c_char_p, [C.c_int]),
+    "ligdiff_weight_numel": (C.c_int64, [C.c_int]),
+    "ligdiff_pack_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "ligdiff_pack_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 9
+                         + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ligdiff_forward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int]),
+    "ligdiff_forward": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
+    "ligdiff_ddpm_step": (C.c_int, [C.POINTER(StepArgs), C.c_void_p]),
+    "ligdiff_ddim_step": (C.c_int, [C.POINTER(StepArgs), C.c_int32, C.c_int32, C.c_void_p]),
+    "ligdiff_ddpm_sample_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int]),
+    "ligdiff_ddpm_sample": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                      C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ligdiff_philox_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64,
+                                        C.c_void_p]),
+}
+
+FWD_PROPERTIES, FWD_NULL_COND, FWD_SKIP_PROP_HEAD, FWD_SAVE_FOR_BACKWARD, FWD_T_BROADCAST = 1, 2, 4, 8, 16
+
+_lib = None
+
+
+class LigdiffError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libligdiff.so and binds every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LigdiffError(f"{LIB_PATH} not found: build the HIP library first (python __graft_entry__.py); "
+                           "there is no CPU fallback for the hot path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ligdiff_version() != 1:
+        raise LigdiffError("libligdiff.so version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().ligdiff_status_string(status).decode()
+        raise LigdiffError(f"{what}: {msg} (status {status})")

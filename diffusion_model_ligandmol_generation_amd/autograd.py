@@ -1,0 +1,32 @@
+"""Glue between the reference's ``model(data, t, properties, cfg)`` call and the engine."""
+import torch
+
+from .engine import PackedGraph
+
+
+def packed_graph_of(data):
+    """Packs ``data`` once and caches the result on the object (a sampler calls the model
+    a thousand times with the same connectivity, generation.py:424)."""
+    g = getattr(data, "_ligdiff_graph", None)
+    ei, batch = data.edge_index, data.batch
+    if g is None or g.key != (ei.data_ptr(), batch.data_ptr(), tuple(ei.shape), batch.numel()):
+        g = PackedGraph(ei, batch)
+        g.key = (ei.data_ptr(), batch.data_ptr(), tuple(ei.shape), batch.numel())
+        try:
+            data._ligdiff_graph = g
+        except AttributeError:
+            pass
+    return g
+
+
+def score_network_apply(model, data, t, properties=None, classifier_free_guidance=False):
+    if not hasattr(data, "batch") or data.batch is None:
+        batch = torch.zeros(data.x.shape[0], dtype=torch.long, device=data.x.device)   # model1.py:702
+        data.batch = batch
+    graph = packed_graph_of(data)
+    eng = model.engine()
+    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+    if needs_grad:
+        from .backward import ScoreNetworkFunction
+        return ScoreNetworkFunction.run(model, eng, graph, data.x, data.pos, t, properties, classifier_free_guidance)
+    return eng.forward(graph, data.x, data.pos, t, properties, null_cond=classifier_free_guidance)

@@ -1,0 +1,58 @@
+// extern "C" surface: argument validation and dispatch (see include/ligdiff.h).
+#include "common.h"
+#include "forward.h"
+#include "weights.h"
+
+extern "C" int ligdiff_version(void) { return LIGDIFF_VERSION; }
+
+extern "C" const char* ligdiff_status_string(int status) {
+  switch (status) {
+    case LIGDIFF_OK: return "ok";
+    case LIGDIFF_ERR_ARG: return "invalid argument (null pointer, negative size or unsupported shape)";
+    case LIGDIFF_ERR_WORKSPACE: return "workspace too small";
+    case LIGDIFF_ERR_LAUNCH: return "HIP launch or graph call failed";
+    case LIGDIFF_ERR_BATCH: return "batch vector not sorted or edge index out of range";
+    case LIGDIFF_ERR_TOO_MANY_ATOMS: return "a molecule has more atoms than the attention kernel supports";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int ligdiff_weight_count(void) { return W_COUNT; }
+extern "C" const char* ligdiff_weight_name(int slot) {
+  return (slot >= 0 && slot < W_COUNT) ? weight_table()[slot].name : nullptr;
+}
+extern "C" int64_t ligdiff_weight_numel(int slot) {
+  return (slot >= 0 && slot < W_COUNT) ? weight_table()[slot].numel : -1;
+}
+
+extern "C" size_t ligdiff_forward_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int flags) {
+  FwdLayout L;
+  fwd_layout(&L, n_atoms, n_edges, n_mols, flags);
+  return L.total;
+}
+
+static int check_graph(const ligdiff_graph* g) {
+  if (!g || g->n_atoms <= 0 || g->n_edges < 0 || g->n_mols <= 0) return LIGDIFF_ERR_ARG;
+  if (g->n_atoms >= (1LL << 30) || g->n_edges >= (1LL << 30)) return LIGDIFF_ERR_ARG;
+  if (!g->mol_ptr || !g->atom_mol || !g->dst_ptr || !g->src_ptr) return LIGDIFF_ERR_ARG;
+  if (g->n_edges > 0 && (!g->src || !g->dst || !g->src_slot)) return LIGDIFF_ERR_ARG;
+  if (g->max_mol_atoms <= 0) return LIGDIFF_ERR_ARG;
+  if (g->max_mol_atoms > LIGDIFF_MAX_ATOMS) return LIGDIFF_ERR_TOO_MANY_ATOMS;
+  return LIGDIFF_OK;
+}
+
+extern "C" int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                               const float* pos, const float* t, const int32_t* t_index_dev,
+                               const float* properties, int flags, float* atom_pred, float* pos_pred,
+                               float* prop_pred, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = check_graph(graph);
+  if (rc) return rc;
+  if (!weights || !x || !pos || (!t && !t_index_dev) || !atom_pred || !pos_pred || !workspace) return LIGDIFF_ERR_ARG;
+  for (int i = 0; i < W_COUNT; ++i)
+    if (weights[i] == nullptr) return LIGDIFF_ERR_ARG;
+  if (t_index_dev && !(flags & LIGDIFF_FWD_T_BROADCAST)) return LIGDIFF_ERR_ARG;
+  if (workspace_bytes < ligdiff_forward_workspace_bytes(graph->n_atoms, graph->n_edges, graph->n_mols, flags))
+    return LIGDIFF_ERR_WORKSPACE;
+  return run_forward(weights, graph, x, pos, t, t_index_dev, properties, flags, atom_pred, pos_pred, prop_pred,
+                     (char*)workspace, (hipStream_t)stream);
+}

@@ -1,0 +1,64 @@
+// Shared device helpers for the gfx950 kernels.  Wavefront = 64 lanes throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ligdiff.h"
+
+#define LD_H 256          // hidden width
+#define LD_A 119          // atom feature width
+#define LD_R 32           // radial basis width
+#define LD_P 15           // property width
+#define LD_HEADS 8
+#define LD_DH 32
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LD_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return LIGDIFF_ERR_LAUNCH; \
+  } while (0)
+
+__device__ __forceinline__ float gelu_exact(float v) {
+  // nn.GELU() default (erf form), model1.py:602 / :615 / :638
+  return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float softplus(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
+
+// d/dv of the activations above (used by the backward kernels)
+__device__ __forceinline__ float gelu_exact_grad(float v) {
+  const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+__device__ __forceinline__ float silu_grad(float v) {
+  const float s = 1.0f / (1.0f + expf(-v));
+  return s * (1.0f + v * (1.0f - s));
+}
+
+// Sum over the 32 lanes of each half-wave (lanes 0-31 and 32-63 reduce separately).
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 1);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 32);
+  return half_wave_sum(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 32));
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 8));
+  v = fmaxf(v, __shfl_xor(v, 4));
+  v = fmaxf(v, __shfl_xor(v, 2));
+  v = fmaxf(v, __shfl_xor(v, 1));
+  return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -1,0 +1,182 @@
+// Model-specific row-wise epilogues for gemm_rows_kernel (see gemm.h for the register map).
+#pragma once
+#include "gemm.h"
+
+// Input embedding, model1.py:709-718:
+//   h = GELU(LN(x Wa^T + ba)) + GELU(LN(pos Wp^T + bp)) + t_emb[mol] (+ prop_emb[mol])
+// The accumulators hold x Wa^T; the 3-wide position projection is done here on the VALU.
+struct EpiEmbed {
+  int M;
+  const float* ba; const float* ga; const float* bea;
+  const float* pos;            // [M,3]
+  const float* Wp;             // [256,3]
+  const float* bp; const float* gp; const float* bep;
+  const float* temb; int temb_stride;   // [B or 1, 256]; stride 0 = one row for all
+  const float* pemb; int pemb_stride;   // nullable
+  const int32_t* atom_mol;
+  float* H;
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[8], int row0, int by, int lane) const {
+    const int c0 = lane & 31;
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      const int rr = row < M ? row : M - 1;
+      const float p0 = pos[(size_t)rr * 3 + 0], p1 = pos[(size_t)rr * 3 + 1], p2 = pos[(size_t)rr * 3 + 2];
+      float v[8], u[8], s = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const int col = ct * 32 + c0;
+        v[ct] = acc[ct][r] + ba[col];
+        // nn.Linear on a 3-vector: sum in k order, then bias
+        u[ct] = (p0 * Wp[col * 3 + 0] + p1 * Wp[col * 3 + 1]) + p2 * Wp[col * 3 + 2] + bp[col];
+        s += v[ct]; s2 += u[ct];
+      }
+      const float m1 = half_wave_sum(s) * (1.0f / 256.0f);
+      const float m2 = half_wave_sum(s2) * (1.0f / 256.0f);
+      float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const float d1 = v[ct] - m1, d2 = u[ct] - m2;
+        q1 += d1 * d1; q2 += d2 * d2;
+      }
+      const float r1 = 1.0f / sqrtf(half_wave_sum(q1) * (1.0f / 256.0f) + 1e-5f);
+      const float r2 = 1.0f / sqrtf(half_wave_sum(q2) * (1.0f / 256.0f) + 1e-5f);
+      if (row < M) {
+        const int mol = atom_mol[row];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+          const int col = ct * 32 + c0;
+          const float y1 = gelu_exact((v[ct] - m1) * r1 * ga[col] + bea[col]);
+          const float y2 = gelu_exact((u[ct] - m2) * r2 * gp[col] + bep[col]);
+          float h = (y1 + y2) + temb[(size_t)mol * temb_stride + col];
+          if (pemb != nullptr) h += pemb[(size_t)mol * pemb_stride + col];
+          H[(size_t)row * 256 + col] = h;
+        }
+      }
+    }
+  }
+};
+
+// adaLN-gated residual, model1.py:295 / :300:  x = resid + gate[mol] * (acc + bias),
+// optionally followed by the NEXT modulated pre-norm (model1.py:293 / :298)
+//   xn = LN(x; eps 1e-6, no affine) * (1 + scale[mol]) + shift[mol].
+template <bool LNMOD>
+struct EpiGate {
+  int M;
+  const float* bias;
+  const float* resid;                       // [M,256]
+  const float* mod; int mod_stride; int gate_off;     // adaLN params of this layer
+  const float* mod2; int shift_off; int scale_off;    // params feeding the next pre-norm
+  const int32_t* atom_mol;
+  float* X;                                 // [M,256]
+  float* XN;                                // [M,256] (LNMOD)
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[8], int row0, int by, int lane) const {
+    const int c0 = lane & 31;
+    float bv[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) bv[ct] = bias[ct * 32 + c0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      const int rr = row < M ? row : M - 1;
+      const int mol = atom_mol[rr];
+      const float* g = mod + (size_t)mol * mod_stride + gate_off;
+      float v[8], s = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const int col = ct * 32 + c0;
+        v[ct] = resid[(size_t)rr * 256 + col] + g[col] * (acc[ct][r] + bv[ct]);
+        s += v[ct];
+      }
+      float mean = 0.f, rstd = 0.f;
+      if (LNMOD) {
+        mean = half_wave_sum(s) * (1.0f / 256.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) { const float d = v[ct] - mean; q += d * d; }
+        rstd = 1.0f / sqrtf(half_wave_sum(q) * (1.0f / 256.0f) + 1e-6f);
+      }
+      if (row < M) {
+        const float* m2 = mod2 + (size_t)mol * mod_stride;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+          const int col = ct * 32 + c0;
+          X[(size_t)row * 256 + col] = v[ct];
+          if (LNMOD)
+            XN[(size_t)row * 256 + col] =
+                ((v[ct] - mean) * rstd) * (1.0f + m2[scale_off + col]) + m2[shift_off + col];
+        }
+      }
+    }
+  }
+};
+
+// First edge-MLP layer split by operand, model1.py:96-97 (Linear 544->256, SiLU):
+//   W1 [h_src | h_dst | rbf] + b1 = Pa[src] + Pb[dst] + Wc rbf + b1
+// with Pa|Pb = h [W1a|W1b]^T computed once per NODE (P is [N,512]); the accumulators hold
+// Wc rbf (K = 32).  Stores SiLU(.) as the A operand of the second edge linear.
+template <bool SAVE>
+struct EpiEdgePre {
+  int M;  // edges
+  const float* b1;
+  const float* P;  // [N,512]
+  const int32_t* src; const int32_t* dst;
+  float* A1;       // [E,256]
+  float* pre_out;  // SAVE: pre-activation
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[8], int row0, int by, int lane) const {
+    const int c0 = lane & 31;
+    float bv[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) bv[ct] = b1[ct * 32 + c0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      if (row < M) {
+        const float* pa = P + (size_t)src[row] * 512;
+        const float* pb = P + (size_t)dst[row] * 512 + 256;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+          const int col = ct * 32 + c0;
+          const float v = (pa[col] + pb[col]) + (acc[ct][r] + bv[ct]);
+          A1[(size_t)row * 256 + col] = silu(v);
+          if (SAVE) pre_out[(size_t)row * 256 + col] = v;
+        }
+      }
+    }
+  }
+};
+
+// Coordinate gate, model1.py:79-84 / :106-107 (NT = 4, 128 hidden units):
+//   cw = tanh(w2 . SiLU(acc + b1) + b2);  wrel = rel * cw
+template <bool SAVE>
+struct EpiCoord {
+  int M;
+  const float* b1;   // [128]
+  const float* w2;   // [128]
+  const float* b2;   // [1]
+  const float* rel;  // [E,4] (xyz + pad)
+  float* wrel;       // [E,4]
+  float* hid_out;    // SAVE: [E,128] pre-activation
+  float* cw_out;     // SAVE: [E]
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[4], int row0, int by, int lane) const {
+    const int c0 = lane & 31;
+    float bv[4], wv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { bv[ct] = b1[ct * 32 + c0]; wv[ct] = w2[ct * 32 + c0]; }
+    const float bias2 = b2[0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      float s = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float u = acc[ct][r] + bv[ct];
+        s += silu(u) * wv[ct];
+        if (SAVE && row < M) hid_out[(size_t)row * 128 + ct * 32 + c0] = u;
+      }
+      const float cw = tanhf(half_wave_sum(s) + bias2);
+      if (row < M && c0 < 3) wrel[(size_t)row * 4 + c0] = rel[(size_t)row * 4 + c0] * cw;
+      if (SAVE && row < M && c0 == 3) cw_out[row] = cw;
+    }
+  }
+};

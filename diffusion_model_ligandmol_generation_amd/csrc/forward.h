@@ -1,0 +1,26 @@
+// Internal interface between the translation units of the library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/ligdiff.h"
+
+// Byte offsets into the forward workspace (all 256-B aligned).
+struct FwdLayout {
+  int64_t Bt;                       // rows of the time tensors: 1 when t is broadcast, else B
+  size_t tf, t1, temb, stemb;       // Fourier features, time-MLP hidden, t_emb, SiLU(t_emb)
+  size_t mod[3];                    // adaLN parameters [Bt,1536] per DiT layer
+  size_t pemb, pstack, pg;          // PILOT embedding, stacked encoders, pareto hidden
+  size_t h0;                        // [N,256] embedding output / residual stream
+  size_t pos_upd, pos_cur;          // [N,3]
+  size_t P[3], rel[3], rbf[3], a1[3], msg[3], wrel[3], agg[3], hid[3], h_e3[3];
+  size_t xn1[3], qkv[3], att[3], x1[3], xn2[3], ffh[3], x2[3];
+  size_t yh;                        // [N,512] head hidden (atom | pos)
+  size_t pooled, ph;                // [B,256]
+  size_t total;
+};
+void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags);
+
+int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
+                const float* t, const int32_t* t_index_dev, const float* properties, int flags,
+                float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s);

@@ -1,0 +1,361 @@
+// Score-network forward: host-side launch sequence + workspace layout.
+#include <stdio.h>
+#include <string.h>
+
+#include "epilogues.h"
+#include "forward.h"
+#include "kernels.h"
+#include "weights.h"
+
+// ------------------------------------------------------------------ weights table
+static void wt_set(WeightInfo* t, int slot, int64_t numel, const char* fmt, int a = 0, int b = 0) {
+  snprintf(t[slot].name, sizeof(t[slot].name), fmt, a, b);
+  t[slot].numel = numel;
+}
+const WeightInfo* weight_table() {
+  static WeightInfo tab[W_COUNT];
+  static const bool once = [] {
+    WeightInfo* t = tab;
+    wt_set(t, W_ATOM_W, 256 * 119, "atom_embedding.0.weight");
+    wt_set(t, W_ATOM_B, 256, "atom_embedding.0.bias");
+    wt_set(t, W_ATOM_G, 256, "atom_embedding.1.weight");
+    wt_set(t, W_ATOM_BE, 256, "atom_embedding.1.bias");
+    wt_set(t, W_POS_W, 256 * 3, "pos_embedding.0.weight");
+    wt_set(t, W_POS_B, 256, "pos_embedding.0.bias");
+    wt_set(t, W_POS_G, 256, "pos_embedding.1.weight");
+    wt_set(t, W_POS_BE, 256, "pos_embedding.1.bias");
+    wt_set(t, W_T0_W, 512 * 256, "time_mlp.0.weight");
+    wt_set(t, W_T0_B, 512, "time_mlp.0.bias");
+    wt_set(t, W_T2_W, 256 * 512, "time_mlp.2.weight");
+    wt_set(t, W_T2_B, 256, "time_mlp.2.bias");
+    wt_set(t, W_NULL_EMB, 256, "property_guidance.null_embedding");
+    wt_set(t, W_PAR0_W, 256 * 2048, "property_guidance.pareto_predictor.0.weight");
+    wt_set(t, W_PAR0_B, 256, "property_guidance.pareto_predictor.0.bias");
+    wt_set(t, W_PAR2_W, 8 * 256, "property_guidance.pareto_predictor.2.weight");
+    wt_set(t, W_PAR2_B, 8, "property_guidance.pareto_predictor.2.bias");
+    for (int i = 0; i < 8; ++i) {
+      wt_set(t, W_PENC(i, 0), 64, "property_guidance.property_encoders.%d.0.weight", i);
+      wt_set(t, W_PENC(i, 1), 64, "property_guidance.property_encoders.%d.0.bias", i);
+      wt_set(t, W_PENC(i, 2), 256 * 64, "property_guidance.property_encoders.%d.2.weight", i);
+      wt_set(t, W_PENC(i, 3), 256, "property_guidance.property_encoders.%d.2.bias", i);
+    }
+    for (int l = 0; l < 3; ++l) {
+      wt_set(t, W_E3(l, E3_RB0_W), 32, "equivariant_layers.%d.radial_basis.0.weight", l);
+      wt_set(t, W_E3(l, E3_RB0_B), 32, "equivariant_layers.%d.radial_basis.0.bias", l);
+      wt_set(t, W_E3(l, E3_RB2_W), 32 * 32, "equivariant_layers.%d.radial_basis.2.weight", l);
+      wt_set(t, W_E3(l, E3_RB2_B), 32, "equivariant_layers.%d.radial_basis.2.bias", l);
+      wt_set(t, W_E3(l, E3_EN0_W), 256 * 544, "equivariant_layers.%d.edge_network.0.weight", l);
+      wt_set(t, W_E3(l, E3_EN0_B), 256, "equivariant_layers.%d.edge_network.0.bias", l);
+      wt_set(t, W_E3(l, E3_EN2_W), 256 * 256, "equivariant_layers.%d.edge_network.2.weight", l);
+      wt_set(t, W_E3(l, E3_EN2_B), 256, "equivariant_layers.%d.edge_network.2.bias", l);
+      wt_set(t, W_E3(l, E3_EN3_G), 256, "equivariant_layers.%d.edge_network.3.weight", l);
+      wt_set(t, W_E3(l, E3_EN3_B), 256, "equivariant_layers.%d.edge_network.3.bias", l);
+      wt_set(t, W_E3(l, E3_NN0_W), 256 * 512, "equivariant_layers.%d.node_network.0.weight", l);
+      wt_set(t, W_E3(l, E3_NN0_B), 256, "equivariant_layers.%d.node_network.0.bias", l);
+      wt_set(t, W_E3(l, E3_NN2_W), 256 * 256, "equivariant_layers.%d.node_network.2.weight", l);
+      wt_set(t, W_E3(l, E3_NN2_B), 256, "equivariant_layers.%d.node_network.2.bias", l);
+      wt_set(t, W_E3(l, E3_NN3_G), 256, "equivariant_layers.%d.node_network.3.weight", l);
+      wt_set(t, W_E3(l, E3_NN3_B), 256, "equivariant_layers.%d.node_network.3.bias", l);
+      wt_set(t, W_E3(l, E3_CN0_W), 128 * 256, "equivariant_layers.%d.coord_network.0.weight", l);
+      wt_set(t, W_E3(l, E3_CN0_B), 128, "equivariant_layers.%d.coord_network.0.bias", l);
+      wt_set(t, W_E3(l, E3_CN2_W), 128, "equivariant_layers.%d.coord_network.2.weight", l);
+      wt_set(t, W_E3(l, E3_CN2_B), 1, "equivariant_layers.%d.coord_network.2.bias", l);
+    }
+    for (int l = 0; l < 3; ++l) {
+      wt_set(t, W_DIT(l, DIT_ADA_W), 1536 * 256, "dit_layers.%d.adaLN_modulation.1.weight", l);
+      wt_set(t, W_DIT(l, DIT_ADA_B), 1536, "dit_layers.%d.adaLN_modulation.1.bias", l);
+      wt_set(t, W_DIT(l, DIT_INP_W), 768 * 256, "dit_layers.%d.attention.in_proj_weight", l);
+      wt_set(t, W_DIT(l, DIT_INP_B), 768, "dit_layers.%d.attention.in_proj_bias", l);
+      wt_set(t, W_DIT(l, DIT_OUT_W), 256 * 256, "dit_layers.%d.attention.out_proj.weight", l);
+      wt_set(t, W_DIT(l, DIT_OUT_B), 256, "dit_layers.%d.attention.out_proj.bias", l);
+      wt_set(t, W_DIT(l, DIT_FF0_W), 1024 * 256, "dit_layers.%d.ff_network.0.weight", l);
+      wt_set(t, W_DIT(l, DIT_FF0_B), 1024, "dit_layers.%d.ff_network.0.bias", l);
+      wt_set(t, W_DIT(l, DIT_FF3_W), 256 * 1024, "dit_layers.%d.ff_network.3.weight", l);
+      wt_set(t, W_DIT(l, DIT_FF3_B), 256, "dit_layers.%d.ff_network.3.bias", l);
+    }
+    const char* heads[3] = {"atom_output", "pos_output", "property_output"};
+    const int outs[3] = {119, 3, 15};
+    for (int h = 0; h < 3; ++h) {
+      char f[96];
+      snprintf(f, sizeof f, "%s.0.weight", heads[h]); wt_set(t, W_HEAD(h, HEAD_W0), 256 * 256, f);
+      snprintf(f, sizeof f, "%s.0.bias", heads[h]);   wt_set(t, W_HEAD(h, HEAD_B0), 256, f);
+      snprintf(f, sizeof f, "%s.2.weight", heads[h]); wt_set(t, W_HEAD(h, HEAD_G), 256, f);
+      snprintf(f, sizeof f, "%s.2.bias", heads[h]);   wt_set(t, W_HEAD(h, HEAD_BE), 256, f);
+      snprintf(f, sizeof f, "%s.3.weight", heads[h]); wt_set(t, W_HEAD(h, HEAD_W3), outs[h] * 256, f);
+      snprintf(f, sizeof f, "%s.3.bias", heads[h]);   wt_set(t, W_HEAD(h, HEAD_B3), outs[h], f);
+    }
+    wt_set(t, W_TIME_FREQS, 128, "__time_freqs__");
+    return true;
+  }();
+  (void)once;
+  return tab;
+}
+
+// ------------------------------------------------------------------ launch helpers
+template <int NT, int WMODE, class AL, class EPI>
+static void launch_gemm(const GemmCore& g, const AL& al, const EPI& epi, int nb, hipStream_t s) {
+  if (g.M <= 0) return;
+  dim3 grid(ceil_div(g.M, G_BM), nb);
+  hipLaunchKernelGGL((gemm_rows_kernel<NT, WMODE, AL, EPI>), grid, dim3(256), 0, s, g, al, epi);
+}
+
+static GemmCore core_blocks(int M, int K, int n_valid, const float* W, int ldw, int nb, int rows_per_block) {
+  GemmCore g;
+  memset(&g, 0, sizeof g);
+  g.M = M; g.K = K; g.n_valid = n_valid; g.ldw = ldw;
+  for (int i = 0; i < nb && i < 8; ++i) g.W[i] = W + (size_t)i * rows_per_block * ldw;
+  return g;
+}
+
+// y[M, nb*256] = act(A[M,K] W^T + b)
+template <int ACT, bool DUAL>
+static void gemm_bias_act(const float* A, int lda, int M, int K, const float* W, int ldw, const float* bias,
+                          int nb, float* C, int ldc, float* C2, hipStream_t s) {
+  GemmCore g = core_blocks(M, K, 256, W, ldw, nb, 256);
+  ALoadPlain al{A, lda, M, K};
+  EpiBiasAct<8, ACT, DUAL> e;
+  memset(&e, 0, sizeof e);
+  e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = ldc; e.C2 = C2; e.alpha = 1.0f;
+  for (int i = 0; i < nb; ++i) e.bias[i] = bias ? bias + (size_t)i * 256 : nullptr;
+  launch_gemm<8, W_ALIGNED>(g, al, e, nb, s);
+}
+
+// ------------------------------------------------------------------ workspace layout
+void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
+  memset(L, 0, sizeof *L);
+  const bool bcast = (flags & LIGDIFF_FWD_T_BROADCAST) != 0;
+  const bool save = (flags & LIGDIFF_FWD_SAVE_FOR_BACKWARD) != 0;
+  const int64_t Bt = bcast ? 1 : B;
+  size_t off = 0;
+  auto take = [&](size_t nfloats) { size_t o = off; off += align_up(nfloats * 4, 256); return o; };
+  L->Bt = Bt;
+  L->tf = take(Bt * 256); L->t1 = take(Bt * 512); L->temb = take(Bt * 256); L->stemb = take(Bt * 256);
+  for (int l = 0; l < 3; ++l) L->mod[l] = take(Bt * 1536);
+  L->pemb = take((size_t)B * 256); L->pstack = take((size_t)B * 2048); L->pg = take((size_t)B * 256);
+  L->h0 = take(N * 256);
+  L->pos_upd = take(N * 3); L->pos_cur = take(N * 3);
+  // Without SAVE every layer reuses layer 0's scratch and the residual stream is updated
+  // in place (each element is read and rewritten by the same thread of the epilogue).
+  auto per_layer = [&](size_t* arr, size_t nfloats) {
+    for (int l = 0; l < 3; ++l) arr[l] = (save || l == 0) ? take(nfloats) : arr[0];
+  };
+  auto stream_buf = [&](size_t* arr) {
+    for (int l = 0; l < 3; ++l) arr[l] = save ? take(N * 256) : L->h0;
+  };
+  per_layer(L->P, N * 512); per_layer(L->rel, E * 4); per_layer(L->rbf, E * 32);
+  per_layer(L->a1, E * 256); per_layer(L->msg, E * 256); per_layer(L->wrel, E * 4);
+  per_layer(L->agg, N * 256); per_layer(L->hid, N * 256);
+  per_layer(L->xn1, N * 256); per_layer(L->qkv, N * 768); per_layer(L->att, N * 256);
+  per_layer(L->xn2, N * 256); per_layer(L->ffh, N * 1024);
+  stream_buf(L->h_e3); stream_buf(L->x1); stream_buf(L->x2);
+  L->yh = take(N * 512);
+  L->pooled = take((size_t)B * 256); L->ph = take((size_t)B * 256);
+  L->total = off;
+}
+
+// ------------------------------------------------------------------ the forward pass
+int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
+                const float* t, const int32_t* t_index_dev, const float* properties, int flags,
+                float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s) {
+  const int N = (int)g->n_atoms, E = (int)g->n_edges, B = g->n_mols;
+  FwdLayout L;
+  fwd_layout(&L, N, E, B, flags);
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+  const int Bt = (int)L.Bt;
+  const int tstride = (flags & LIGDIFF_FWD_T_BROADCAST) ? 0 : 256;
+  const int mstride = (flags & LIGDIFF_FWD_T_BROADCAST) ? 0 : 1536;
+
+  // --- time embedding (model1.py:705-706) and adaLN parameters (model1.py:288)
+  hipLaunchKernelGGL(k_fourier, dim3(Bt), dim3(128), 0, s, t, t_index_dev, w[W_TIME_FREQS], F(L.tf));
+  gemm_bias_act<ACT_GELU, false>(F(L.tf), 256, Bt, 256, w[W_T0_W], 256, w[W_T0_B], 2, F(L.t1), 512, nullptr, s);
+  gemm_bias_act<ACT_NONE, true>(F(L.t1), 512, Bt, 512, w[W_T2_W], 512, w[W_T2_B], 1, F(L.temb), 256, F(L.stemb), s);
+  for (int l = 0; l < 3; ++l)
+    gemm_bias_act<ACT_NONE, false>(F(L.stemb), 256, Bt, 256, w[W_DIT(l, DIT_ADA_W)], 256, w[W_DIT(l, DIT_ADA_B)], 6,
+                                   F(L.mod[l]), 1536, nullptr, s);
+
+  // --- PILOT conditioning (model1.py:714-718, :335-359)
+  const float* pemb = nullptr;
+  int pstride = 0;
+  if (flags & LIGDIFF_FWD_PROPERTIES) {
+    if (flags & LIGDIFF_FWD_NULL_COND) {
+      pemb = w[W_NULL_EMB]; pstride = 0;
+    } else {
+      if (properties == nullptr) return LIGDIFF_ERR_ARG;
+      PilotEncWeights pw;
+      for (int i = 0; i < 8; ++i) {
+        pw.w0[i] = w[W_PENC(i, 0)]; pw.b0[i] = w[W_PENC(i, 1)];
+        pw.W2[i] = w[W_PENC(i, 2)]; pw.b2[i] = w[W_PENC(i, 3)];
+      }
+      hipLaunchKernelGGL(k_pilot_encode, dim3(B), dim3(256), 0, s, properties, pw, F(L.pstack));
+      gemm_bias_act<ACT_GELU, false>(F(L.pstack), 2048, B, 2048, w[W_PAR0_W], 2048, w[W_PAR0_B], 1, F(L.pg), 256, nullptr, s);
+      hipLaunchKernelGGL(k_pilot_combine, dim3(B), dim3(256), 0, s, F(L.pg), w[W_PAR2_W], w[W_PAR2_B], F(L.pstack), F(L.pemb));
+      pemb = F(L.pemb); pstride = 256;
+    }
+  }
+
+  // --- input embeddings (model1.py:709-711)
+  {
+    GemmCore gc = core_blocks(N, LD_A, 256, w[W_ATOM_W], LD_A, 1, 256);
+    ALoadScalar al{x, LD_A, N, LD_A};
+    EpiEmbed e;
+    e.M = N; e.ba = w[W_ATOM_B]; e.ga = w[W_ATOM_G]; e.bea = w[W_ATOM_BE];
+    e.pos = pos; e.Wp = w[W_POS_W]; e.bp = w[W_POS_B]; e.gp = w[W_POS_G]; e.bep = w[W_POS_BE];
+    e.temb = F(L.temb); e.temb_stride = tstride; e.pemb = pemb; e.pemb_stride = pstride;
+    e.atom_mol = g->atom_mol; e.H = F(L.h0);
+    launch_gemm<8, W_SCALAR>(gc, al, e, 1, s);
+  }
+
+  // --- E(3) message-passing layers (model1.py:721-725, :86-114)
+  const float* h_in = F(L.h0);
+  for (int l = 0; l < 3; ++l) {
+    const float* pos_l = (l == 0) ? pos : F(L.pos_cur);
+    // per-node halves of the first edge linear: P = h [W1a | W1b]^T
+    {
+      GemmCore gc;
+      memset(&gc, 0, sizeof gc);
+      gc.M = N; gc.K = 256; gc.n_valid = 256; gc.ldw = 544;
+      gc.W[0] = w[W_E3(l, E3_EN0_W)]; gc.W[1] = w[W_E3(l, E3_EN0_W)] + 256;
+      ALoadPlain al{h_in, 256, N, 256};
+      EpiBiasAct<8, ACT_NONE, false> e;
+      memset(&e, 0, sizeof e);
+      e.M = N; e.n_valid = 256; e.col_block = 256; e.C = F(L.P[l]); e.ldc = 512; e.alpha = 1.0f;
+      launch_gemm<8, W_ALIGNED>(gc, al, e, 2, s);
+    }
+    if (E > 0) {
+      hipLaunchKernelGGL(k_edge_geom, dim3(ceil_div(E, 256)), dim3(256), 0, s, pos_l, g->src, g->dst,
+                         w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB0_B)], w[W_E3(l, E3_RB2_W)], w[W_E3(l, E3_RB2_B)],
+                         F(L.rel[l]), F(L.rbf[l]), (float*)nullptr, E);
+      {  // a1 = SiLU(Pa[src] + Pb[dst] + Wc rbf + b1)
+        GemmCore gc;
+        memset(&gc, 0, sizeof gc);
+        gc.M = E; gc.K = 32; gc.n_valid = 256; gc.ldw = 544; gc.W[0] = w[W_E3(l, E3_EN0_W)] + 512;
+        ALoadPlain al{F(L.rbf[l]), 32, E, 32};
+        EpiEdgePre<false> e{E, w[W_E3(l, E3_EN0_B)], F(L.P[l]), g->src, g->dst, F(L.a1[l]), nullptr};
+        launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      }
+      {  // msg = LN(a1 W2^T + b2)
+        GemmCore gc = core_blocks(E, 256, 256, w[W_E3(l, E3_EN2_W)], 256, 1, 256);
+        ALoadPlain al{F(L.a1[l]), 256, E, 256};
+        EpiLN<ACT_NONE, ACT_NONE, false, false> e;
+        memset(&e, 0, sizeof e);
+        e.M = E; e.bias[0] = w[W_E3(l, E3_EN2_B)]; e.gamma[0] = w[W_E3(l, E3_EN3_G)]; e.beta[0] = w[W_E3(l, E3_EN3_B)];
+        e.eps = 1e-5f; e.C = F(L.msg[l]); e.ldc = 256;
+        launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      }
+      {  // wrel = rel * tanh(w2 . SiLU(msg Wc1^T + b) + b2)
+        GemmCore gc = core_blocks(E, 256, 128, w[W_E3(l, E3_CN0_W)], 256, 1, 128);
+        ALoadPlain al{F(L.msg[l]), 256, E, 256};
+        EpiCoord<false> e{E, w[W_E3(l, E3_CN0_B)], w[W_E3(l, E3_CN2_W)], w[W_E3(l, E3_CN2_B)],
+                          F(L.rel[l]), F(L.wrel[l]), nullptr, nullptr};
+        launch_gemm<4, W_ALIGNED>(gc, al, e, 1, s);
+      }
+    }
+    hipLaunchKernelGGL(k_aggregate, dim3(ceil_div(N, 4)), dim3(256), 0, s, F(L.msg[l]), F(L.wrel[l]), g->dst_ptr,
+                       g->src_ptr, g->src_slot, pos, F(L.pos_upd), F(L.pos_cur), F(L.agg[l]), (float*)nullptr, N,
+                       l == 0 ? 1 : 0);
+    {  // hid = SiLU([h | agg] Wn1^T + b)
+      GemmCore gc = core_blocks(N, 512, 256, w[W_E3(l, E3_NN0_W)], 512, 1, 256);
+      ALoadConcat al{h_in, F(L.agg[l]), 256, 256, 256, N, 512};
+      EpiBiasAct<8, ACT_SILU, false> e;
+      memset(&e, 0, sizeof e);
+      e.M = N; e.n_valid = 256; e.col_block = 256; e.bias[0] = w[W_E3(l, E3_NN0_B)]; e.C = F(L.hid[l]); e.ldc = 256;
+      e.alpha = 1.0f;
+      launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+    }
+    {  // h = h + LN(hid Wn2^T + b)
+      GemmCore gc = core_blocks(N, 256, 256, w[W_E3(l, E3_NN2_W)], 256, 1, 256);
+      ALoadPlain al{F(L.hid[l]), 256, N, 256};
+      EpiLN<ACT_NONE, ACT_NONE, true, false> e;
+      memset(&e, 0, sizeof e);
+      e.M = N; e.bias[0] = w[W_E3(l, E3_NN2_B)]; e.gamma[0] = w[W_E3(l, E3_NN3_G)]; e.beta[0] = w[W_E3(l, E3_NN3_B)];
+      e.eps = 1e-5f; e.C = F(L.h_e3[l]); e.ldc = 256; e.resid = h_in; e.ldr = 256;
+      launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+    }
+    h_in = F(L.h_e3[l]);
+  }
+
+  // --- adaLN attention layers over each molecule's own atoms (model1.py:728-738, :279-302)
+  const int max_n = g->max_mol_atoms;
+  const float* x_in = h_in;
+  hipLaunchKernelGGL(k_ln_mod, dim3(ceil_div(N, 4)), dim3(256), 0, s, x_in, F(L.mod[0]), mstride, 0, 256,
+                     g->atom_mol, F(L.xn1[0]), N);
+  for (int l = 0; l < 3; ++l) {
+    gemm_bias_act<ACT_NONE, false>(F(L.xn1[l]), 256, N, 256, w[W_DIT(l, DIT_INP_W)], 256, w[W_DIT(l, DIT_INP_B)], 3,
+                                   F(L.qkv[l]), 768, nullptr, s);
+    if (max_n <= 32) {
+      const size_t lds = (size_t)4 * 2 * 32 * 64 * 4;
+      hipLaunchKernelGGL(k_attention<32>, dim3(B), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]),
+                         (float*)nullptr, 32);
+    } else {
+      const int mn = max_n <= 64 ? 64 : 128;
+      const size_t lds = (size_t)4 * mn * 64 * 4;
+      hipLaunchKernelGGL(k_attention<64>, dim3(B * 2), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]),
+                         (float*)nullptr, mn);
+    }
+    {  // x1 = x + gate_msa * (att Wo^T + b);  xn2 = LN(x1)(1+scale_mlp)+shift_mlp
+      GemmCore gc = core_blocks(N, 256, 256, w[W_DIT(l, DIT_OUT_W)], 256, 1, 256);
+      ALoadPlain al{F(L.att[l]), 256, N, 256};
+      EpiGate<true> e{N, w[W_DIT(l, DIT_OUT_B)], x_in, F(L.mod[l]), mstride, 512, F(L.mod[l]), 768, 1024,
+                      g->atom_mol, F(L.x1[l]), F(L.xn2[l])};
+      launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+    }
+    gemm_bias_act<ACT_GELU, false>(F(L.xn2[l]), 256, N, 256, w[W_DIT(l, DIT_FF0_W)], 256, w[W_DIT(l, DIT_FF0_B)], 4,
+                                   F(L.ffh[l]), 1024, nullptr, s);
+    {  // x2 = x1 + gate_mlp * (ffh W3^T + b); next layer's xn1 fused
+      GemmCore gc = core_blocks(N, 1024, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1, 256);
+      ALoadPlain al{F(L.ffh[l]), 1024, N, 1024};
+      if (l < 2) {
+        EpiGate<true> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l + 1]), 0, 256,
+                        g->atom_mol, F(L.x2[l]), F(L.xn1[l + 1])};
+        launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      } else {
+        EpiGate<false> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l]), 0, 256,
+                         g->atom_mol, F(L.x2[l]), nullptr};
+        launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      }
+    }
+    x_in = F(L.x2[l]);
+  }
+
+  // --- heads (model1.py:741-746)
+  {
+    GemmCore gc;
+    memset(&gc, 0, sizeof gc);
+    gc.M = N; gc.K = 256; gc.n_valid = 256; gc.ldw = 256;
+    gc.W[0] = w[W_HEAD(0, HEAD_W0)]; gc.W[1] = w[W_HEAD(1, HEAD_W0)];
+    ALoadPlain al{x_in, 256, N, 256};
+    EpiLN<ACT_GELU, ACT_NONE, false, false> e;
+    memset(&e, 0, sizeof e);
+    e.M = N; e.eps = 1e-5f; e.C = F(L.yh); e.ldc = 512;
+    for (int hd = 0; hd < 2; ++hd) {
+      e.bias[hd] = w[W_HEAD(hd, HEAD_B0)]; e.gamma[hd] = w[W_HEAD(hd, HEAD_G)]; e.beta[hd] = w[W_HEAD(hd, HEAD_BE)];
+    }
+    launch_gemm<8, W_ALIGNED>(gc, al, e, 2, s);
+  }
+  {  // atom_pred = y_atom W3^T + b   (119 outputs)
+    GemmCore gc = core_blocks(N, 256, LD_A, w[W_HEAD(0, HEAD_W3)], 256, 1, 128);
+    ALoadPlain al{F(L.yh), 512, N, 256};
+    EpiBiasAct<4, ACT_NONE, false> e;
+    memset(&e, 0, sizeof e);
+    e.M = N; e.n_valid = LD_A; e.col_block = 0; e.bias[0] = w[W_HEAD(0, HEAD_B3)]; e.C = atom_pred; e.ldc = LD_A;
+    e.alpha = 1.0f;
+    launch_gemm<4, W_ALIGNED>(gc, al, e, 1, s);
+  }
+  hipLaunchKernelGGL(k_head_small<3>, dim3(ceil_div(N, 4)), dim3(256), 0, s, F(L.yh), 512, 256, w[W_HEAD(1, HEAD_W3)],
+                     w[W_HEAD(1, HEAD_B3)], F(L.pos_upd), pos_pred, N);
+  if (!(flags & LIGDIFF_FWD_SKIP_PROP_HEAD)) {
+    if (prop_pred == nullptr) return LIGDIFF_ERR_ARG;
+    hipLaunchKernelGGL(k_mean_pool, dim3(ceil_div(B, 4)), dim3(256), 0, s, x_in, g->mol_ptr, F(L.pooled), B);
+    GemmCore gc = core_blocks(B, 256, 256, w[W_HEAD(2, HEAD_W0)], 256, 1, 256);
+    ALoadPlain al{F(L.pooled), 256, B, 256};
+    EpiLN<ACT_GELU, ACT_NONE, false, false> e;
+    memset(&e, 0, sizeof e);
+    e.M = B; e.eps = 1e-5f; e.C = F(L.ph); e.ldc = 256;
+    e.bias[0] = w[W_HEAD(2, HEAD_B0)]; e.gamma[0] = w[W_HEAD(2, HEAD_G)]; e.beta[0] = w[W_HEAD(2, HEAD_BE)];
+    launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+    hipLaunchKernelGGL(k_head_small<15>, dim3(ceil_div(B, 4)), dim3(256), 0, s, F(L.ph), 256, 0, w[W_HEAD(2, HEAD_W3)],
+                       w[W_HEAD(2, HEAD_B3)], (const float*)nullptr, prop_pred, B);
+  }
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}

@@ -1,0 +1,280 @@
+// Non-GEMM kernels of the score-network forward (gather / scatter / normalisation /
+// attention).  All are HBM- or latency-bound VALU kernels; one wave handles one row,
+// one destination node or one (molecule, head) so that every global access is a
+// contiguous 128-B..1-KiB segment.
+#pragma once
+#include "common.h"
+
+// Fourier features, model1.py:686-697.  freqs[128] is computed on the host with the
+// reference's own expression; t is the per-molecule value or one device-side step index.
+__global__ void k_fourier(const float* __restrict__ t, const int32_t* __restrict__ t_index,
+                          const float* __restrict__ freqs, float* __restrict__ out) {
+  const int b = blockIdx.x, k = threadIdx.x;  // 128 threads
+  const float tv = t_index != nullptr ? (float)(*t_index) : t[b];
+  const float e = tv * freqs[k];
+  out[(size_t)b * 256 + k] = sinf(e);
+  out[(size_t)b * 256 + 128 + k] = cosf(e);
+}
+
+// Edge geometry + radial MLP, model1.py:88-93, one lane per CSR edge:
+//   rel = pos[dst] - pos[src];  d = ||rel + 1e-8||;  rbf = W2 SiLU(w0 d + b0) + b2
+__global__ __launch_bounds__(256) void k_edge_geom(
+    const float* __restrict__ pos, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+    const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ W2,
+    const float* __restrict__ b2, float* __restrict__ rel, float* __restrict__ rbf,
+    float* __restrict__ dist_out, int E) {
+  __shared__ float sW2[32 * 32];
+  __shared__ float sw0[32], sb0[32], sb2[32];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 1024; i += 256) sW2[i] = W2[i];
+  if (tid < 32) { sw0[tid] = w0[tid]; sb0[tid] = b0[tid]; sb2[tid] = b2[tid]; }
+  __syncthreads();
+  const int e = blockIdx.x * 256 + tid;
+  if (e >= E) return;
+  const int s = src[e], d = dst[e];
+  const float rx = pos[(size_t)d * 3 + 0] - pos[(size_t)s * 3 + 0];
+  const float ry = pos[(size_t)d * 3 + 1] - pos[(size_t)s * 3 + 1];
+  const float rz = pos[(size_t)d * 3 + 2] - pos[(size_t)s * 3 + 2];
+  const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
+  const float dist = sqrtf(ex * ex + ey * ey + ez * ez);
+  f32x4 rv = {rx, ry, rz, 0.f};
+  *reinterpret_cast<f32x4*>(rel + (size_t)e * 4) = rv;
+  if (dist_out != nullptr) dist_out[e] = dist;
+  float r1[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) r1[j] = silu(dist * sw0[j] + sb0[j]);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int jo = q * 4 + c;
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) a += sW2[jo * 32 + j] * r1[j];
+      o[c] = a + sb2[jo];
+    }
+    *reinterpret_cast<f32x4*>(rbf + (size_t)e * 32 + q * 4) = o;
+  }
+}
+
+// Message aggregation + coordinate scatter, model1.py:100 / :110-112 / :724-725.
+// One wave per destination atom.  The atom's incoming messages are CONTIGUOUS rows of
+// msg (CSR order), so the sum streams 1-KiB rows, 16 B per lane, in the fixed edge order
+// of a sequential index_add_ (bit-reproducible, no atomics).
+//   agg[i]      = sum_{e in in(i)} msg[e]
+//   dpos[i]     = sum_{e in in(i)} wrel[e] - sum_{e in out(i)} wrel[e]
+//   pos_upd[i] += 0.1 dpos[i];  pos_cur[i] = pos[i] + pos_upd[i]
+__global__ __launch_bounds__(256) void k_aggregate(
+    const float* __restrict__ msg, const float* __restrict__ wrel,
+    const int32_t* __restrict__ dst_ptr, const int32_t* __restrict__ src_ptr,
+    const int32_t* __restrict__ src_slot, const float* __restrict__ pos,
+    float* __restrict__ pos_upd, float* __restrict__ pos_cur, float* __restrict__ agg,
+    float* __restrict__ dpos_out, int N, int first_layer) {
+  const int lane = threadIdx.x & 63;
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (node >= N) return;
+  const int e0 = dst_ptr[node], e1 = dst_ptr[node + 1];
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
+  int e = e0;
+  for (; e + 4 <= e1; e += 4) {  // 4 rows in flight per wave
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(msg + (size_t)(e + 0) * 256 + lane * 4);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(msg + (size_t)(e + 1) * 256 + lane * 4);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(msg + (size_t)(e + 2) * 256 + lane * 4);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(msg + (size_t)(e + 3) * 256 + lane * 4);
+    a0 = (((a0 + v0) + v1) + v2) + v3;
+  }
+  for (; e < e1; ++e) a0 += *reinterpret_cast<const f32x4*>(msg + (size_t)e * 256 + lane * 4);
+  *reinterpret_cast<f32x4*>(agg + (size_t)node * 256 + lane * 4) = a0;
+
+  const int c = lane & 3;
+  float d = 0.f;
+  for (int k = e0 + (lane >> 2); k < e1; k += 16) d += wrel[(size_t)k * 4 + c];
+  const int s0 = src_ptr[node], s1 = src_ptr[node + 1];
+  for (int k = s0 + (lane >> 2); k < s1; k += 16) d -= wrel[(size_t)src_slot[k] * 4 + c];
+  d += __shfl_xor(d, 4);
+  d += __shfl_xor(d, 8);
+  d += __shfl_xor(d, 16);
+  d += __shfl_xor(d, 32);
+  if (lane < 3) {
+    const size_t o = (size_t)node * 3 + lane;
+    if (dpos_out != nullptr) dpos_out[o] = d;
+    const float pu = (first_layer ? 0.f : pos_upd[o]) + d * 0.1f;
+    pos_upd[o] = pu;
+    pos_cur[o] = pos[o] + pu;
+  }
+}
+
+// xn = LN(x; eps 1e-6, no affine) * (1 + scale[mol]) + shift[mol]   (model1.py:293)
+__global__ __launch_bounds__(256) void k_ln_mod(const float* __restrict__ x, const float* __restrict__ mod,
+                                                int mod_stride, int shift_off, int scale_off,
+                                                const int32_t* __restrict__ atom_mol,
+                                                float* __restrict__ xn, int N) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * 256 + lane * 4);
+  const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+  const f32x4 dlt = v - mean;
+  const float var = wave_sum((dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3])) * (1.0f / 256.0f);
+  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  const float* m = mod + (size_t)atom_mol[row] * mod_stride;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(m + scale_off + lane * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(m + shift_off + lane * 4);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (dlt[i] * rstd) * (1.0f + sc[i]) + sh[i];
+  *reinterpret_cast<f32x4*>(xn + (size_t)row * 256 + lane * 4) = o;
+}
+
+// Per-molecule multi-head attention over the molecule's OWN atoms (8 heads x 32),
+// model1.py:294 with nn.MultiheadAttention semantics.  Equal, for every real atom, to the
+// reference's pad-to-max_atoms batch with key_padding_mask: masked keys get weight
+// exactly 0 and padded query rows are dropped (model1.py:736-738).
+// A group of G lanes serves one head (one query atom per lane, G = 32 or 64); the head's
+// K and V rows sit in LDS and are read as broadcasts.  Softmax is the two-pass
+// max / exp / sum form.  qkv is [N,768] = [q | k | v].
+template <int G>
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv,
+                                                   const int32_t* __restrict__ mol_ptr,
+                                                   float* __restrict__ out, float* __restrict__ lse_out,
+                                                   int max_n) {
+  constexpr int HPW = 64 / G;            // heads per wave
+  constexpr int BPM = 8 / (4 * HPW);     // blocks per molecule
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mol = blockIdx.x / BPM, hb = blockIdx.x % BPM;
+  const int a0 = mol_ptr[mol];
+  const int n = mol_ptr[mol + 1] - a0;
+  const int head0 = (hb * 4 + wave) * HPW;
+  float* kv = smem + (size_t)wave * HPW * max_n * 64;
+  for (int i = lane; i < n * HPW * 16; i += 64) {
+    const int j = i / (HPW * 16), rem = i % (HPW * 16);
+    const int hh = rem >> 4, part = rem & 15;
+    const float* sp = qkv + (size_t)(a0 + j) * 768 + (part < 8 ? 256 : 512) + (head0 + hh) * 32 + (part & 7) * 4;
+    *reinterpret_cast<f32x4*>(kv + ((size_t)hh * max_n + j) * 64 + part * 4) = *reinterpret_cast<const f32x4*>(sp);
+  }
+  __syncthreads();
+  const int hh = lane / G;
+  const float* kvh = kv + (size_t)hh * max_n * 64;
+  const float scale = 0.17677669529663687f;  // 1/sqrt(32)
+  for (int qi = lane % G; qi < n; qi += G) {
+    f32x4 q[8];
+    const float* qp = qkv + (size_t)(a0 + qi) * 768 + (head0 + hh) * 32;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) q[d] = *reinterpret_cast<const f32x4*>(qp + d * 4);
+    float m = -INFINITY;
+    for (int j = 0; j < n; ++j) {
+      const float* kp = kvh + (size_t)j * 64;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + d * 4);
+        s += q[d][0] * kk[0] + q[d][1] * kk[1] + q[d][2] * kk[2] + q[d][3] * kk[3];
+      }
+      m = fmaxf(m, s * scale);
+    }
+    float l = 0.f;
+    f32x4 o[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < n; ++j) {
+      const float* kp = kvh + (size_t)j * 64;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + d * 4);
+        s += q[d][0] * kk[0] + q[d][1] * kk[1] + q[d][2] * kk[2] + q[d][3] * kk[3];
+      }
+      const float p = expf(s * scale - m);
+      l += p;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) o[d] += p * *reinterpret_cast<const f32x4*>(kp + 32 + d * 4);
+    }
+    const float inv = 1.0f / l;
+    float* op = out + (size_t)(a0 + qi) * 256 + (head0 + hh) * 32;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) *reinterpret_cast<f32x4*>(op + d * 4) = o[d] * inv;
+    if (lse_out != nullptr) lse_out[(size_t)(a0 + qi) * 8 + head0 + hh] = m + logf(l);
+  }
+}
+
+// out[row, o] = y[row, off:off+256] . W[o, :] + b[o] (+ add[row, o]); final layers of
+// the coordinate (3) and property (15) heads, model1.py:647 / :654 / :742.
+template <int NOUT>
+__global__ __launch_bounds__(256) void k_head_small(const float* __restrict__ y, int ldy, int off,
+                                                    const float* __restrict__ W, const float* __restrict__ b,
+                                                    const float* __restrict__ add, float* __restrict__ out, int M) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(y + (size_t)row * ldy + off + lane * 4);
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)o * 256 + lane * 4);
+    float s = wave_sum((v[0] * w[0] + v[1] * w[1]) + (v[2] * w[2] + v[3] * w[3]));
+    if (lane == 0) {
+      s += b[o];
+      if (add != nullptr) s += add[(size_t)row * NOUT + o];
+      out[(size_t)row * NOUT + o] = s;
+    }
+  }
+}
+
+// global_mean_pool(h, batch), model1.py:745: one wave per molecule.
+__global__ __launch_bounds__(256) void k_mean_pool(const float* __restrict__ h, const int32_t* __restrict__ mol_ptr,
+                                                   float* __restrict__ out, int B) {
+  const int lane = threadIdx.x & 63;
+  const int mol = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (mol >= B) return;
+  const int a0 = mol_ptr[mol], a1 = mol_ptr[mol + 1];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int a = a0; a < a1; ++a) s += *reinterpret_cast<const f32x4*>(h + (size_t)a * 256 + lane * 4);
+  const float inv = 1.0f / (float)(a1 - a0 > 0 ? a1 - a0 : 1);
+  *reinterpret_cast<f32x4*>(out + (size_t)mol * 256 + lane * 4) = s * inv;
+}
+
+// PILOT property encoders, model1.py:341-351: stacked[b, i, :] = W2_i GELU(w0_i p_i + b0_i) + b2_i
+struct PilotEncWeights { const float* w0[8]; const float* b0[8]; const float* W2[8]; const float* b2[8]; };
+__global__ __launch_bounds__(256) void k_pilot_encode(const float* __restrict__ props, PilotEncWeights w,
+                                                      float* __restrict__ stacked) {
+  __shared__ float hid[8][64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 512; i += 256) {
+    const int e = i >> 6, j = i & 63;
+    hid[e][j] = gelu_exact(props[(size_t)b * LD_P + e] * w.w0[e][j] + w.b0[e][j]);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int e = 0; e < 8; ++e) {
+    const float* W2 = w.W2[e] + (size_t)tid * 64;
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) a += W2[j] * hid[e][j];
+    stacked[(size_t)b * 2048 + e * 256 + tid] = a + w.b2[e][tid];
+  }
+}
+
+// Pareto weights + weighted sum, model1.py:354-359:
+//   w = softplus(W g + b);  w /= sum(w);  out = sum_i w_i stacked[b, i, :]
+__global__ __launch_bounds__(256) void k_pilot_combine(const float* __restrict__ g, const float* __restrict__ W,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ stacked,
+                                                       float* __restrict__ out) {
+  __shared__ float wsm[8];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (size_t)b * 256 + lane * 4);
+  for (int o = wave; o < 8; o += 4) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(W + (size_t)o * 256 + lane * 4);
+    const float s = wave_sum((gv[0] * wv[0] + gv[1] * wv[1]) + (gv[2] * wv[2] + gv[3] * wv[3]));
+    if (lane == 0) wsm[o] = softplus(s + bias[o]);
+  }
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) tot += wsm[o];
+  float a = 0.f;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) a += stacked[(size_t)b * 2048 + o * 256 + tid] * (wsm[o] / tot);
+  out[(size_t)b * 256 + tid] = a;
+}

@@ -1,0 +1,144 @@
+// Ragged batch -> CSR packing on device (integer, deterministic, bit-exact).
+//
+// Edges are grouped by destination atom with their original order kept inside each group
+// (the order a sequential index_add_ would visit them, model1.py:100 / :110-112), and a
+// second index lists, per source atom, the CSR slots of the edges that leave it.
+#include "common.h"
+
+__global__ void k_pack_zero(int32_t* buf, int64_t n, int32_t* status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) buf[i] = 0;
+  if (i == 0) { status[0] = 0; status[1] = 0; }
+}
+
+// atom_mol = (int32) batch, sortedness / range check, mol_ptr boundaries.
+__global__ void k_pack_mols(const int64_t* __restrict__ batch, int64_t N, int32_t B, int32_t* __restrict__ atom_mol,
+                            int32_t* __restrict__ mol_ptr, int32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int64_t b = batch[i];
+  if (b < 0 || b >= B) { atomicOr(&status[0], LIGDIFF_ERR_BATCH); return; }
+  atom_mol[i] = (int32_t)b;
+  const int64_t prev = (i == 0) ? -1 : batch[i - 1];
+  if (prev > b) { atomicOr(&status[0], LIGDIFF_ERR_BATCH); return; }
+  for (int64_t m = prev + 1; m <= b; ++m) mol_ptr[m] = (int32_t)i;  // also covers empty molecules
+  if (i == N - 1)
+    for (int64_t m = b + 1; m <= B; ++m) mol_ptr[m] = (int32_t)N;
+}
+
+__global__ void k_pack_maxmol(const int32_t* __restrict__ mol_ptr, int32_t B, int32_t* __restrict__ status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) atomicMax(&status[1], mol_ptr[i + 1] - mol_ptr[i]);
+}
+
+__global__ void k_pack_count(const int64_t* __restrict__ ei, int64_t E, int64_t N, int32_t* __restrict__ deg,
+                             int32_t* __restrict__ sdeg, int32_t* __restrict__ status) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = ei[e], d = ei[E + e];
+  if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(&status[0], LIGDIFF_ERR_BATCH); return; }
+  atomicAdd(&deg[d], 1);
+  atomicAdd(&sdeg[s], 1);
+}
+
+// Exclusive scan of cnt[0..n) into ptr[0..n]; one 1024-thread block walks the array.
+__global__ __launch_bounds__(1024) void k_pack_scan(const int32_t* __restrict__ cnt, int64_t n, int32_t* __restrict__ ptr) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + tid;
+    const int32_t v = (i < n) ? cnt[i] : 0;
+    int32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w2 = 0; w2 < wave; ++w2) woff += wsum[w2];
+    const int32_t c = carry;
+    if (i < n) ptr[i] = c + woff + x - v;
+    __syncthreads();
+    if (tid == 1023) carry = c + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) ptr[n] = carry;
+}
+
+// Drop item i into the bucket of key[i] (order inside a bucket fixed afterwards).
+__global__ void k_pack_fill_dst(const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ ptr,
+                                int32_t* __restrict__ cursor, int32_t* __restrict__ perm, const int32_t* status) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E || status[0] != 0) return;
+  const int32_t d = (int32_t)ei[E + e];
+  perm[ptr[d] + atomicAdd(&cursor[d], 1)] = (int32_t)e;
+}
+
+// Ascending sort of every bucket: restores the original (stable) order.
+__global__ void k_pack_sort_buckets(const int32_t* __restrict__ ptr, int32_t* __restrict__ items, int64_t N,
+                                    const int32_t* status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N || status[0] != 0) return;
+  const int32_t b = ptr[i], e = ptr[i + 1];
+  for (int32_t a = b + 1; a < e; ++a) {
+    const int32_t v = items[a];
+    int32_t j = a - 1;
+    while (j >= b && items[j] > v) { items[j + 1] = items[j]; --j; }
+    items[j + 1] = v;
+  }
+}
+
+__global__ void k_pack_emit(const int64_t* __restrict__ ei, int64_t E, const int32_t* __restrict__ perm,
+                            int32_t* __restrict__ src, int32_t* __restrict__ dst, const int32_t* __restrict__ src_ptr,
+                            int32_t* __restrict__ cursor, int32_t* __restrict__ src_slot, const int32_t* status) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E || status[0] != 0) return;
+  const int32_t e = perm[k];
+  const int32_t s = (int32_t)ei[e], d = (int32_t)ei[E + e];
+  src[k] = s;
+  dst[k] = d;
+  src_slot[src_ptr[s] + atomicAdd(&cursor[s], 1)] = (int32_t)k;
+}
+
+extern "C" size_t ligdiff_pack_workspace_bytes(int64_t n_atoms, int64_t n_edges) {
+  (void)n_edges;
+  return (size_t)(4 * (n_atoms + 1)) * sizeof(int32_t);
+}
+
+extern "C" int ligdiff_pack_csr(const int64_t* edge_index, int64_t E, const int64_t* batch, int64_t N, int32_t B,
+                                int32_t* mol_ptr, int32_t* atom_mol, int32_t* dst_ptr, int32_t* src, int32_t* dst,
+                                int32_t* perm, int32_t* src_ptr, int32_t* src_slot, int32_t* status_dev,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (N <= 0 || E < 0 || B <= 0 || !batch || !mol_ptr || !atom_mol || !dst_ptr || !src_ptr || !status_dev || !workspace)
+    return LIGDIFF_ERR_ARG;
+  if (E > 0 && (!edge_index || !src || !dst || !perm || !src_slot)) return LIGDIFF_ERR_ARG;
+  if (N >= (1LL << 30) || E >= (1LL << 30)) return LIGDIFF_ERR_ARG;
+  if (workspace_bytes < ligdiff_pack_workspace_bytes(N, E)) return LIGDIFF_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* deg = (int32_t*)workspace;
+  int32_t* sdeg = deg + (N + 1);
+  int32_t* cur = sdeg + (N + 1);
+  int32_t* cur2 = cur + (N + 1);
+  const int64_t nz = 4 * (N + 1);
+  hipLaunchKernelGGL(k_pack_zero, dim3(ceil_div(nz, 256)), dim3(256), 0, s, deg, nz, status_dev);
+  hipLaunchKernelGGL(k_pack_mols, dim3(ceil_div(N, 256)), dim3(256), 0, s, batch, N, B, atom_mol, mol_ptr, status_dev);
+  hipLaunchKernelGGL(k_pack_maxmol, dim3(ceil_div(B, 256)), dim3(256), 0, s, mol_ptr, B, status_dev);
+  if (E > 0)
+    hipLaunchKernelGGL(k_pack_count, dim3(ceil_div(E, 256)), dim3(256), 0, s, edge_index, E, N, deg, sdeg, status_dev);
+  hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, s, deg, N, dst_ptr);
+  hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(1024), 0, s, sdeg, N, src_ptr);
+  if (E > 0) {
+    hipLaunchKernelGGL(k_pack_fill_dst, dim3(ceil_div(E, 256)), dim3(256), 0, s, edge_index, E, dst_ptr, cur, perm, status_dev);
+    hipLaunchKernelGGL(k_pack_sort_buckets, dim3(ceil_div(N, 256)), dim3(256), 0, s, dst_ptr, perm, N, status_dev);
+    hipLaunchKernelGGL(k_pack_emit, dim3(ceil_div(E, 256)), dim3(256), 0, s, edge_index, E, perm, src, dst, src_ptr, cur2,
+                       src_slot, status_dev);
+    hipLaunchKernelGGL(k_pack_sort_buckets, dim3(ceil_div(N, 256)), dim3(256), 0, s, src_ptr, src_slot, N, status_dev);
+  }
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}

@@ -1,0 +1,251 @@
+// Reverse-diffusion updates (generation.py:457-484 DDPM, :359-381 DDIM) and the
+// graph-captured sampling loop (generation.py:422).
+#include <string.h>
+
+#include "common.h"
+#include "forward.h"
+
+// ------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// Four N(0,1) draws for the quad of elements [4q, 4q+4) of stream `sid` at step `step`.
+// The counter is the GLOBAL quad index, so the draw for an element does not depend on how
+// molecules are split over GPUs or launches.
+__device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t step, uint32_t sid, uint64_t quad) {
+  uint32_t c[4] = {(uint32_t)quad, (uint32_t)(quad >> 32), step, sid};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float k = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)c[0] + 0.5f) * k, u1 = ((float)c[1] + 0.5f) * k;
+  const float u2 = ((float)c[2] + 0.5f) * k, u3 = ((float)c[3] + 0.5f) * k;
+  const float r0 = sqrtf(-2.0f * logf(fminf(u0, 0.99999994f) + 1e-30f));
+  const float r1 = sqrtf(-2.0f * logf(fminf(u2, 0.99999994f) + 1e-30f));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  return (f32x4){r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+}
+
+__global__ void k_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, uint32_t sid, int64_t offset) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t g = (uint64_t)(offset + i);
+  const f32x4 z = philox_normal4(seed, step, sid, g >> 2);
+  out[i] = z[g & 3];
+}
+
+extern "C" int ligdiff_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, uint32_t stream_id,
+                                     int64_t offset, void* stream) {
+  if (!out || n < 0 || offset < 0) return LIGDIFF_ERR_ARG;
+  if (n == 0) return LIGDIFF_OK;
+  hipLaunchKernelGGL(k_philox_normal, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, step,
+                     stream_id, offset);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}
+
+// ------------------------------------------------------------------ fused step kernels
+struct StepCoef {  // scalars of one reverse update: v <- a * (v - b * eps) + c * z
+  float a, b, c;
+  int add_noise;
+};
+
+__device__ __forceinline__ StepCoef ddpm_coef(const float* betas, const float* alphas, const float* abar, int t,
+                                              float temperature) {
+  StepCoef k;
+  if (t > 0) {
+    const float beta = betas[t];
+    k.a = 1.0f / sqrtf(alphas[t]);
+    k.b = beta / sqrtf(1.0f - abar[t]);
+    k.c = sqrtf(beta);
+    k.add_noise = t > 1;
+  } else {  // final step: (v - sqrt(1-abar_0) eps) / sqrt(abar_0)
+    k.a = 0.f; k.b = sqrtf(1.0f - abar[0]); k.c = sqrtf(abar[0]);
+    k.add_noise = 0;
+  }
+  (void)temperature;
+  return k;
+}
+
+// One thread per element.  stream id 0 = atom features, 1 = coordinates.
+template <bool DDIM>
+__global__ __launch_bounds__(256) void k_reverse_step(ligdiff_step_args a, int t_cur_arg, int t_next_arg) {
+  const int64_t nx = a.n_atoms * LD_A, np = a.n_atoms * 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nx + np) return;
+  const bool is_pos = i >= nx;
+  const int64_t j = is_pos ? i - nx : i;
+  float* state = is_pos ? a.pos : a.x;
+  const float* ec = is_pos ? a.eps_pos : a.eps_x;
+  const float* eu = is_pos ? a.eps_pos_uncond : a.eps_x_uncond;
+  float eps = ec[j];
+  if (eu != nullptr) {  // generation.py:442-443
+    const float u = eu[j];
+    eps = u + a.guidance_scale * (eps - u);
+  }
+  const float v = state[j];
+  float out;
+  if (DDIM) {
+    const float at = a.alphas_cumprod[t_cur_arg];
+    const float x0 = (v - sqrtf(1.0f - at) * eps) / sqrtf(at);
+    if (t_next_arg >= 0) {
+      const float an = a.alphas_cumprod[t_next_arg];
+      out = sqrtf(an) * x0 + sqrtf(1.0f - an) * eps;
+    } else {
+      out = x0;
+    }
+  } else {
+    const int t = *a.t_index_dev;
+    const StepCoef k = ddpm_coef(a.betas, a.alphas, a.alphas_cumprod, t, a.temperature);
+    if (t > 0) {
+      out = k.a * (v - k.b * eps);
+      if (k.add_noise) {
+        float z;
+        const float* nz = is_pos ? a.noise_pos : a.noise_x;
+        if (nz != nullptr) {
+          z = nz[j];
+        } else {
+          const uint64_t g = (uint64_t)(a.atom_offset * (is_pos ? 3 : LD_A) + j);
+          z = philox_normal4(a.seed, (uint32_t)t, is_pos ? 1u : 0u, g >> 2)[g & 3];
+        }
+        out += (z * k.c) * a.temperature;
+      }
+    } else {
+      out = (v - k.b * eps) / k.c;
+    }
+  }
+  state[j] = out;
+}
+
+__global__ void k_add_int(int32_t* p, int32_t d) { *p += d; }
+__global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
+
+static int check_step_args(const ligdiff_step_args* a) {
+  if (!a || !a->x || !a->pos || !a->eps_x || !a->eps_pos || a->n_atoms <= 0) return LIGDIFF_ERR_ARG;
+  if ((a->eps_x_uncond == nullptr) != (a->eps_pos_uncond == nullptr)) return LIGDIFF_ERR_ARG;
+  if ((a->noise_x == nullptr) != (a->noise_pos == nullptr)) return LIGDIFF_ERR_ARG;
+  return LIGDIFF_OK;
+}
+
+extern "C" int ligdiff_ddpm_step(const ligdiff_step_args* a, void* stream) {
+  int rc = check_step_args(a);
+  if (rc) return rc;
+  if (!a->betas || !a->alphas || !a->alphas_cumprod || !a->t_index_dev) return LIGDIFF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = a->n_atoms * (LD_A + 3);
+  hipLaunchKernelGGL(k_reverse_step<false>, dim3(ceil_div(n, 256)), dim3(256), 0, s, *a, 0, 0);
+  hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s, a->t_index_dev, -1);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}
+
+extern "C" int ligdiff_ddim_step(const ligdiff_step_args* a, int32_t t_cur, int32_t t_next, void* stream) {
+  int rc = check_step_args(a);
+  if (rc) return rc;
+  if (!a->alphas_cumprod || t_cur < 0) return LIGDIFF_ERR_ARG;
+  const int64_t n = a->n_atoms * (LD_A + 3);
+  hipLaunchKernelGGL(k_reverse_step<true>, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, *a, t_cur, t_next);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}
+
+// ------------------------------------------------------------------ whole DDPM loop
+struct SampleLayout { size_t fwd, eps_x, eps_pos, eps_xu, eps_pu, t_index, total; };
+static void sample_layout(SampleLayout* L, int64_t N, int64_t E, int32_t B, int guided) {
+  FwdLayout F;
+  fwd_layout(&F, N, E, B, LIGDIFF_FWD_T_BROADCAST);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  L->fwd = take(F.total);
+  L->eps_x = take((size_t)N * LD_A * 4); L->eps_pos = take((size_t)N * 3 * 4);
+  L->eps_xu = guided ? take((size_t)N * LD_A * 4) : 0;
+  L->eps_pu = guided ? take((size_t)N * 3 * 4) : 0;
+  L->t_index = take(256);
+  L->total = off;
+}
+
+extern "C" size_t ligdiff_ddpm_sample_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided) {
+  SampleLayout L;
+  sample_layout(&L, n_atoms, n_edges, n_mols, guided);
+  return L.total;
+}
+
+extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                                   const float* properties, float guidance_scale, float temperature,
+                                   const float* betas, const float* alphas, const float* alphas_cumprod,
+                                   int32_t n_steps, uint64_t seed, int64_t atom_offset, int use_graph,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!weights || !graph || !x || !pos || !betas || !alphas || !alphas_cumprod || !workspace || n_steps <= 0)
+    return LIGDIFF_ERR_ARG;
+  // generation.py:428: guidance only when properties are given AND scale > 1
+  const int guided = (properties != nullptr && guidance_scale > 1.0f) ? 1 : 0;
+  SampleLayout L;
+  sample_layout(&L, graph->n_atoms, graph->n_edges, graph->n_mols, guided);
+  if (workspace_bytes < L.total) return LIGDIFF_ERR_WORKSPACE;
+  char* ws = (char*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* t_index = (int32_t*)(ws + L.t_index);
+
+  ligdiff_step_args a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.pos = pos;
+  a.eps_x = (float*)(ws + L.eps_x); a.eps_pos = (float*)(ws + L.eps_pos);
+  if (guided) { a.eps_x_uncond = (float*)(ws + L.eps_xu); a.eps_pos_uncond = (float*)(ws + L.eps_pu); }
+  a.guidance_scale = guidance_scale; a.temperature = temperature;
+  a.betas = betas; a.alphas = alphas; a.alphas_cumprod = alphas_cumprod;
+  a.t_index_dev = t_index; a.seed = seed; a.atom_offset = atom_offset; a.n_atoms = graph->n_atoms;
+
+  const int base = LIGDIFF_FWD_T_BROADCAST | LIGDIFF_FWD_SKIP_PROP_HEAD;
+  auto one_step = [&]() -> int {
+    int rc = run_forward(weights, graph, x, pos, nullptr, t_index, properties,
+                         base | (properties ? LIGDIFF_FWD_PROPERTIES : 0), (float*)(ws + L.eps_x),
+                         (float*)(ws + L.eps_pos), nullptr, ws + L.fwd, s);
+    if (rc) return rc;
+    if (guided) {
+      rc = run_forward(weights, graph, x, pos, nullptr, t_index, nullptr, base, (float*)(ws + L.eps_xu),
+                       (float*)(ws + L.eps_pu), nullptr, ws + L.fwd, s);
+      if (rc) return rc;
+    }
+    return ligdiff_ddpm_step(&a, s);
+  };
+
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, t_index, n_steps - 1);
+  if (!use_graph) {
+    for (int i = 0; i < n_steps; ++i) {
+      int rc = one_step();
+      if (rc) return rc;
+    }
+    return LIGDIFF_OK;
+  }
+  // One reverse step is captured once; the step index lives in device memory and is
+  // decremented by the graph itself, so the same executable graph serves every step.
+  hipGraph_t graph_h = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return LIGDIFF_ERR_LAUNCH;
+  int rc = one_step();
+  hipError_t he = hipStreamEndCapture(s, &graph_h);
+  if (rc || he != hipSuccess || graph_h == nullptr) {
+    if (graph_h) (void)hipGraphDestroy(graph_h);
+    return rc ? rc : LIGDIFF_ERR_LAUNCH;
+  }
+  if (hipGraphInstantiate(&exec, graph_h, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGraphDestroy(graph_h);
+    return LIGDIFF_ERR_LAUNCH;
+  }
+  rc = LIGDIFF_OK;
+  for (int i = 0; i < n_steps; ++i)
+    if (hipGraphLaunch(exec, s) != hipSuccess) { rc = LIGDIFF_ERR_LAUNCH; break; }
+  // the executable graph must outlive its queued launches
+  if (hipStreamSynchronize(s) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph_h);
+  return rc;
+}

@@ -1,0 +1,175 @@
+"""Host-side plumbing between PyTorch tensors and the C-ABI library.
+
+PyTorch owns every buffer (weights, states, workspaces); this module only turns them into
+raw device pointers, packs ragged batches into the CSR layout and enqueues the library's
+entry points on the current HIP stream.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import Graph, check
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device: the hot path has no CPU implementation")
+
+
+class PackedGraph:
+    """Device-resident CSR form of a ragged batch (struct ligdiff_graph).
+
+    Built from the reference's own batch layout: ``edge_index`` [2,E] int64 with
+    edge_index[1] the aggregation target (model1.py:88-100) and ``batch`` [N] int64 sorted
+    ascending (PyG collate, main.py:205-212).
+    """
+
+    def __init__(self, edge_index, batch, num_mols=None):
+        lib = _lib.load()
+        _require_cuda(batch, "batch")
+        dev = batch.device
+        batch = batch.contiguous().to(torch.int64)
+        N = batch.numel()
+        if N == 0:
+            raise ValueError("empty batch")
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E] (a molecule without bonds needs an empty [2, 0] tensor)")
+        edge_index = edge_index.contiguous().to(device=dev, dtype=torch.int64)
+        E = edge_index.shape[1]
+        B = int(batch.max().item()) + 1 if num_mols is None else int(num_mols)   # model1.py:702
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.mol_ptr = torch.empty(B + 1, **i32)
+        self.atom_mol = torch.empty(N, **i32)
+        self.dst_ptr = torch.empty(N + 1, **i32)
+        self.src_ptr = torch.empty(N + 1, **i32)
+        self.src = torch.empty(max(E, 1), **i32)
+        self.dst = torch.empty(max(E, 1), **i32)
+        self.perm = torch.empty(max(E, 1), **i32)
+        self.src_slot = torch.empty(max(E, 1), **i32)
+        status = torch.zeros(2, **i32)
+        ws_bytes = lib.ligdiff_pack_workspace_bytes(N, E)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.ligdiff_pack_csr(_ptr(edge_index), E, _ptr(batch), N, B, _ptr(self.mol_ptr), _ptr(self.atom_mol),
+                                      _ptr(self.dst_ptr), _ptr(self.src), _ptr(self.dst), _ptr(self.perm),
+                                      _ptr(self.src_ptr), _ptr(self.src_slot), _ptr(status), _ptr(ws), ws_bytes,
+                                      _stream())
+        check(rc, "ligdiff_pack_csr")
+        st = status.tolist()
+        check(st[0], "ligdiff_pack_csr (device validation)")
+        self.n_atoms, self.n_edges, self.n_mols, self.max_mol_atoms = N, E, B, int(st[1])
+        self.device = dev
+        self.batch = batch
+        self.c = Graph(N, E, B, self.max_mol_atoms, self.mol_ptr.data_ptr(), self.atom_mol.data_ptr(),
+                       self.dst_ptr.data_ptr(), self.src.data_ptr(), self.dst.data_ptr(), self.perm.data_ptr(),
+                       self.src_ptr.data_ptr(), self.src_slot.data_ptr())
+
+
+def time_frequencies(hidden_dim=256):
+    """The 128 Fourier frequencies of model1.py:688-690: exp(arange * -(ln 1e4 / 127)).
+    The argument is formed in fp32 as the reference does; the exponential is evaluated in
+    fp64 and rounded once, so the table is the same on every host CPU (a vectorised fp32
+    exp differs between machines in the last bit, which a step index near 1000 would
+    amplify into a visible phase difference)."""
+    half = hidden_dim // 2
+    emb = math.log(10000) / (half - 1)
+    arg = torch.arange(half, dtype=torch.float32) * -emb
+    return torch.exp(arg.double()).float()
+
+
+class ScoreNetworkEngine:
+    """Weights table + workspace cache of one model on one device."""
+
+    def __init__(self, model):
+        self.lib = _lib.load()
+        params = dict(model.state_dict(keep_vars=True))
+        any_p = params["time_mlp.0.weight"]
+        _require_cuda(any_p, "model")
+        self.device = any_p.device
+        self.freqs = time_frequencies(model.hidden_dim).to(self.device)
+        n = self.lib.ligdiff_weight_count()
+        self.names = [self.lib.ligdiff_weight_name(i).decode() for i in range(n)]
+        self.table = (C.c_void_p * n)()
+        self._sig = []
+        for i, name in enumerate(self.names):
+            t = self.freqs if name == "__time_freqs__" else params[name]
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise RuntimeError(f"weight {name} must be a contiguous fp32 tensor on {self.device}")
+            if t.numel() != self.lib.ligdiff_weight_numel(i):
+                raise RuntimeError(f"weight {name} has {t.numel()} elements, expected {self.lib.ligdiff_weight_numel(i)}")
+            self.table[i] = t.data_ptr()
+            self._sig.append(t.data_ptr())
+        self._params = params
+        self._ws = None
+        self.max_atoms = model.max_atoms
+
+    def stale(self, model):
+        sd = model.state_dict(keep_vars=True)
+        for i, name in enumerate(self.names):
+            if name != "__time_freqs__" and sd[name].data_ptr() != self._sig[i]:
+                return True
+        return False
+
+    def workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, graph, x, pos, t, properties=None, null_cond=False, want_props=True, save=False,
+                workspace=None):
+        """ligdiff_forward on the current stream.  t: [B] float tensor (or [1], applied to
+        every molecule).  Returns atom_pred, pos_pred, prop_pred (None if not wanted)."""
+        N, B = graph.n_atoms, graph.n_mols
+        if graph.max_mol_atoms > self.max_atoms:
+            raise RuntimeError(f"a molecule has {graph.max_mol_atoms} atoms but the model was built with "
+                               f"max_atoms={self.max_atoms} (model1.py:728)")
+        for name, v in (("x", x), ("pos", pos), ("t", t)):
+            _require_cuda(v, name)
+        x = x.contiguous().float()
+        pos = pos.contiguous().float()
+        t = t.reshape(-1).contiguous().float()
+        if x.shape != (N, 119) or pos.shape != (N, 3):
+            raise ValueError("x must be [N,119] and pos [N,3]")
+        flags = 0
+        if t.numel() == 1 and B > 1:
+            flags |= _lib.FWD_T_BROADCAST
+        elif t.numel() < B:
+            raise ValueError("t needs one value per molecule")
+        if properties is not None:
+            flags |= _lib.FWD_PROPERTIES
+            if null_cond:
+                flags |= _lib.FWD_NULL_COND
+            else:
+                properties = properties.contiguous().float()
+                if properties.shape[0] != B or properties.shape[1] < 8:
+                    raise ValueError("properties must be [B, >=8] (a [B,15] tensor in the reference)")
+                if properties.shape[1] != 15:
+                    p15 = properties.new_zeros(B, 15)
+                    p15[:, :min(15, properties.shape[1])] = properties[:, :15]
+                    properties = p15
+        if not want_props:
+            flags |= _lib.FWD_SKIP_PROP_HEAD
+        if save:
+            flags |= _lib.FWD_SAVE_FOR_BACKWARD
+        nbytes = self.lib.ligdiff_forward_workspace_bytes(N, graph.n_edges, B, flags)
+        ws = workspace if workspace is not None else self.workspace(nbytes)
+        atom_pred = torch.empty(N, 119, dtype=torch.float32, device=self.device)
+        pos_pred = torch.empty(N, 3, dtype=torch.float32, device=self.device)
+        prop_pred = torch.empty(B, 15, dtype=torch.float32, device=self.device) if want_props else None
+        with torch.cuda.device(self.device):
+            rc = self.lib.ligdiff_forward(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(t), None,
+                                          _ptr(properties) if (properties is not None and not null_cond) else None,
+                                          flags, _ptr(atom_pred), _ptr(pos_pred), _ptr(prop_pred), _ptr(ws),
+                                          ws.numel(), _stream())
+        check(rc, "ligdiff_forward")
+        return atom_pred, pos_pred, prop_pred

@@ -1,0 +1,179 @@
+/*
+ * ligdiff.h - C ABI of the MI355X (gfx950) ligand-diffusion hot path.
+ *
+ * Plain pointers and sizes only; every pointer named *_dev / every float* / int32_t* /
+ * int64_t* argument is a DEVICE pointer unless its comment says "host".  The library
+ * keeps no global state and (outside ligdiff_sampler_*, which owns a hipGraph) never
+ * allocates: the caller owns all buffers and passes a workspace.  Every entry point
+ * takes the hipStream_t (as void*) it enqueues on and returns an int status, 0 = ok.
+ *
+ * The reference (Nishanth-nishu/diffusion_model_ligandmol_generation) is pure Python on
+ * PyTorch with no FFI of its own; each entry point below names the reference code it
+ * replaces.  The Python classes in diffusion_model_ligandmol_generation_amd/ keep the
+ * reference's call signatures and reach these functions through ctypes.
+ */
+#ifndef LIGDIFF_H
+#define LIGDIFF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIGDIFF_VERSION 1
+
+/* model constants the kernels are tiled for (model1.py:574-587 defaults) */
+#define LIGDIFF_HIDDEN 256
+#define LIGDIFF_HEADS 8
+#define LIGDIFF_ATOM_DIM 119
+#define LIGDIFF_PROP_DIM 15
+#define LIGDIFF_RADIAL 32
+#define LIGDIFF_E3_LAYERS 3
+#define LIGDIFF_DIT_LAYERS 3
+#define LIGDIFF_MAX_ATOMS 128
+
+enum ligdiff_status {
+  LIGDIFF_OK = 0,
+  LIGDIFF_ERR_ARG = 1,        /* null pointer / negative size / unsupported shape        */
+  LIGDIFF_ERR_WORKSPACE = 2,  /* workspace smaller than ligdiff_*_workspace_bytes says   */
+  LIGDIFF_ERR_LAUNCH = 3,     /* a HIP launch or graph call failed (hipGetLastError)     */
+  LIGDIFF_ERR_BATCH = 4,      /* batch vector not sorted / edge index out of range       */
+  LIGDIFF_ERR_TOO_MANY_ATOMS = 5
+};
+
+int ligdiff_version(void);
+const char* ligdiff_status_string(int status);
+
+/* ---------------------------------------------------------------------------------
+ * Weights table.  One slot per tensor of the reference's state_dict that the hot path
+ * reads (model1.py:595-655), fp32, [out, in] row-major exactly as nn.Linear stores it.
+ * ligdiff_weight_name(i) returns the state_dict key of slot i so a host binding can fill
+ * the table by name; ligdiff_weight_numel(i) the element count it must have.
+ * ------------------------------------------------------------------------------- */
+int ligdiff_weight_count(void);
+const char* ligdiff_weight_name(int slot);
+int64_t ligdiff_weight_numel(int slot);
+
+/* ---------------------------------------------------------------------------------
+ * Packed ragged batch.  Replaces the PyG collate + per-call index arithmetic of
+ * model1.py:88-112 / :728 (data_utils.py:898-914 defines the per-molecule arrays).
+ * Built on device by ligdiff_pack_csr from the reference's own tensors.
+ * ------------------------------------------------------------------------------- */
+typedef struct ligdiff_graph {
+  int64_t n_atoms;            /* N                                                      */
+  int64_t n_edges;            /* E (directed)                                           */
+  int32_t n_mols;             /* B                                                      */
+  int32_t max_mol_atoms;      /* largest molecule, <= LIGDIFF_MAX_ATOMS                 */
+  const int32_t* mol_ptr;     /* [B+1] first atom of each molecule                      */
+  const int32_t* atom_mol;    /* [N]   molecule of each atom (int32 copy of `batch`)    */
+  const int32_t* dst_ptr;     /* [N+1] CSR offsets, edges grouped by edge_index[1]      */
+  const int32_t* src;         /* [E]   edge_index[0] in CSR order                       */
+  const int32_t* dst;         /* [E]   edge_index[1] in CSR order                       */
+  const int32_t* perm;        /* [E]   original edge id of each CSR slot (stable)       */
+  const int32_t* src_ptr;     /* [N+1] offsets of the by-source list                    */
+  const int32_t* src_slot;    /* [E]   CSR slots of the edges leaving each atom         */
+} ligdiff_graph;
+
+/* Bytes of int32 scratch ligdiff_pack_csr needs for N atoms / E edges. */
+size_t ligdiff_pack_workspace_bytes(int64_t n_atoms, int64_t n_edges);
+
+/*
+ * edge_index [2,E] int64 and batch [N] int64 (sorted ascending) -> the int32 arrays of
+ * ligdiff_graph (caller-allocated: mol_ptr B+1, atom_mol N, dst_ptr N+1, src/dst/perm E,
+ * src_ptr N+1, src_slot E).  Edges keep their original order inside each destination
+ * group, so sums over a group run in the order of a sequential index_add_.
+ * status_dev[0] receives 0, or LIGDIFF_ERR_BATCH if validation failed; status_dev[1]
+ * receives the largest molecule size.  Integer results are bit-exact and deterministic.
+ */
+int ligdiff_pack_csr(const int64_t* edge_index, int64_t n_edges, const int64_t* batch,
+                     int64_t n_atoms, int32_t n_mols, int32_t* mol_ptr, int32_t* atom_mol,
+                     int32_t* dst_ptr, int32_t* src, int32_t* dst, int32_t* perm,
+                     int32_t* src_ptr, int32_t* src_slot, int32_t* status_dev,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Score-network forward.  Replaces ResearchAccurateDiffusionModel.forward in eval mode
+ * (model1.py:699-755): embeddings, 3 E(3) message-passing layers (model1.py:86-114),
+ * 3 adaLN attention layers over each molecule's own atoms (model1.py:279-302; equal to
+ * the reference's pad-to-max_atoms + key_padding_mask for every real atom), heads.
+ * ------------------------------------------------------------------------------- */
+enum ligdiff_forward_flags {
+  LIGDIFF_FWD_PROPERTIES = 1,   /* properties [B,15] given (model1.py:714-718)           */
+  LIGDIFF_FWD_NULL_COND = 2,    /* classifier_free_guidance=True: learned null vector     */
+  LIGDIFF_FWD_SKIP_PROP_HEAD = 4, /* do not compute prop_pred (samplers ignore it)        */
+  LIGDIFF_FWD_SAVE_FOR_BACKWARD = 8, /* keep activations in the workspace for backward    */
+  LIGDIFF_FWD_T_BROADCAST = 16  /* t has ONE element used for every molecule              */
+};
+
+size_t ligdiff_forward_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int flags);
+
+/*
+ * weights: host array of ligdiff_weight_count() device pointers.
+ * x [N,119], pos [N,3], t [B] (or [1] with LIGDIFF_FWD_T_BROADCAST; the value fed to the
+ * Fourier embedding: integer step for the samplers, c_noise for the trainer),
+ * properties [B,15] or NULL.  Outputs atom_pred [N,119], pos_pred [N,3], prop_pred [B,15]
+ * (may be NULL with LIGDIFF_FWD_SKIP_PROP_HEAD).
+ * t_index_dev: if non-NULL, a device int32; the time value used is (float)*t_index_dev
+ * for every molecule and `t` is ignored (lets a captured graph step through time).
+ */
+int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                    const float* pos, const float* t, const int32_t* t_index_dev,
+                    const float* properties, int flags, float* atom_pred, float* pos_pred,
+                    float* prop_pred, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused reverse-diffusion updates.  Replace the per-step tensor arithmetic of
+ * generation.py:457-484 (DDPM) and generation.py:359-381 (DDIM): schedule lookup,
+ * optional classifier-free combination (generation.py:442-443), Gaussian noise and the
+ * posterior update of BOTH state tensors in one kernel.
+ * ------------------------------------------------------------------------------- */
+typedef struct ligdiff_step_args {
+  float* x;                  /* [N,119] state, updated in place                         */
+  float* pos;                /* [N,3]   state, updated in place                         */
+  const float* eps_x;        /* [N,119] conditional (or only) prediction                */
+  const float* eps_pos;      /* [N,3]                                                    */
+  const float* eps_x_uncond; /* NULL, or unconditional prediction for guidance           */
+  const float* eps_pos_uncond;
+  float guidance_scale;
+  float temperature;
+  const float* betas;        /* [T] model buffers (model1.py:658-663)                    */
+  const float* alphas;
+  const float* alphas_cumprod;
+  int32_t* t_index_dev;      /* device int32: current step t; decremented by the kernel */
+  const float* noise_x;      /* NULL -> in-kernel Philox; else [N,119] N(0,1) draws     */
+  const float* noise_pos;    /* NULL -> in-kernel Philox; else [N,3]                    */
+  uint64_t seed;             /* Philox key                                               */
+  int64_t atom_offset;       /* global index of atom 0 (keeps draws independent of how   */
+                             /* molecules are sharded over GPUs)                         */
+  int64_t n_atoms;
+} ligdiff_step_args;
+
+int ligdiff_ddpm_step(const ligdiff_step_args* args, void* stream);
+
+/* DDIM: t_cur / t_next indices into alphas_cumprod; t_next < 0 means the final step. */
+int ligdiff_ddim_step(const ligdiff_step_args* args, int32_t t_cur, int32_t t_next, void* stream);
+
+/*
+ * Whole 1000-step DDPM loop of generation.py:422-484 for a packed batch of molecules:
+ * captures one reverse step (forward [+ unconditional forward] + fused update) into a
+ * hipGraph on `stream` and replays it n_steps times.  x / pos hold the initial noise on
+ * entry and the sample on return.  properties NULL -> unguided.
+ */
+int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                        const float* properties, float guidance_scale, float temperature,
+                        const float* betas, const float* alphas, const float* alphas_cumprod,
+                        int32_t n_steps, uint64_t seed, int64_t atom_offset, int use_graph,
+                        void* workspace, size_t workspace_bytes, void* stream);
+size_t ligdiff_ddpm_sample_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided);
+
+/* Fills out[n] with the N(0,1) draws the in-kernel Philox stream yields for
+ * (seed, step, global element index offset..offset+n): lets a host reproduce a run. */
+int ligdiff_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, uint32_t stream_id,
+                          int64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGDIFF_H */

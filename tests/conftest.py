@@ -36,11 +36,13 @@ def seed0_model(**kw):
             if k.startswith("moldiff_consistency.") and ("max_valences" in k or "covalent_radii" in k):
                 continue  # RDKit-derived constants: inputs of a checkpoint, not of the seed
             if k in ("betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod",
-                     "sqrt_one_minus_alphas_cumprod") and kw.get("timesteps", 1000) != 1000:
-                continue
+                     "sqrt_one_minus_alphas_cumprod"):
+                continue  # schedule buffers: not seeded weights (checked against schedule.npz)
             v = sd[k].double()
             got = np.array([float(v.sum()), float(v.abs().sum()), float(v.flatten()[0]), float(v.flatten()[-1])])
-            assert np.array_equal(got, ck[k]), f"seed-0 weight {k} differs from the reference's"
+            # first / last element exact; the fp64 sums only to reduction-order rounding
+            assert np.array_equal(got[2:], ck[k][2:]) and np.allclose(got[:2], ck[k][:2], rtol=1e-11, atol=1e-13), \
+                f"seed-0 weight {k} differs from the reference's"
         _MODELS[key] = m
     return _MODELS[key]
 
