@@ -54,7 +54,12 @@ SIGNATURES = {
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                       C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ligdiff_philox_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64,
-                                        C.c_void_p]),
+                                        C.c_float, C.c_void_p]),
+    "ligdiff_template_edge_count": (C.c_int64, [C.c_int32]),
+    "ligdiff_template_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    "ligdiff_prediction_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ligdiff_validity_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 
 FWD_PROPERTIES, FWD_NULL_COND, FWD_SKIP_PROP_HEAD, FWD_SAVE_FOR_BACKWARD, FWD_T_BROADCAST = 1, 2, 4, 8, 16

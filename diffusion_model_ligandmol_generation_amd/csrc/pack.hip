@@ -142,3 +142,56 @@ extern "C" int ligdiff_pack_csr(const int64_t* edge_index, int64_t E, const int6
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;
 }
+
+// ------------------------------------------------------------------ template connectivity
+// Device form of the generator's deterministic bond template (generation.py:562-668) for a
+// whole batch of molecule sizes; one thread per bond, closed form in the bond index k:
+//   n <= 5        chain            bond k = (k, k+1)
+//   6 <= n <= 15  ring + subst.    k < 6: (k, (k+1)%6);  else s = k-6: ((2s)%6, 6+s)
+//   n >= 16       fused rings      k < 6 ring; k < 11: (6+i, 6+(i+1)%5), i = k-6;
+//                                  k = 11: (1,6); k = 12: (2,10); else s = k-13: (s%11, 11+s)
+// Bond k of a molecule whose first atom is a0 and first directed edge is e0 writes
+// (a,b) to edge e0+2k and (b,a) to e0+2k+1.  kind[e] = 1 for ring/fusion (aromatic) bonds.
+__host__ __device__ inline int template_bonds(int n) {
+  if (n <= 1) return 0;
+  if (n <= 5) return n - 1;
+  if (n <= 15) return n;
+  return n + 2;
+}
+
+__global__ void k_template_edges(const int32_t* __restrict__ mol_ptr, const int64_t* __restrict__ edge_ptr, int32_t B,
+                                 int32_t max_bonds, int64_t E, int64_t* __restrict__ edge_index,
+                                 uint8_t* __restrict__ kind) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int mol = (int)(gid / max_bonds), k = (int)(gid % max_bonds);
+  if (mol >= B) return;
+  const int a0 = mol_ptr[mol], n = mol_ptr[mol + 1] - a0;
+  if (k >= template_bonds(n)) return;
+  int a, b, arom;
+  if (n <= 5) { a = k; b = k + 1; arom = 0; }
+  else if (k < 6) { a = k; b = (k + 1) % 6; arom = 1; }
+  else if (n <= 15) { const int s = k - 6; a = (2 * s) % 6; b = 6 + s; arom = 0; }
+  else if (k < 11) { const int i = k - 6; a = 6 + i; b = 6 + (i + 1) % 5; arom = 1; }
+  else if (k == 11) { a = 1; b = 6; arom = 1; }
+  else if (k == 12) { a = 2; b = 10; arom = 1; }
+  else { const int s = k - 13; a = s % 11; b = 11 + s; arom = 0; }
+  const int64_t e = edge_ptr[mol] + 2 * (int64_t)k;
+  edge_index[e] = a0 + a;     edge_index[E + e] = a0 + b;
+  edge_index[e + 1] = a0 + b; edge_index[E + e + 1] = a0 + a;
+  if (kind != nullptr) { kind[e] = (uint8_t)arom; kind[e + 1] = (uint8_t)arom; }
+}
+
+extern "C" int64_t ligdiff_template_edge_count(int32_t n_atoms) { return 2 * (int64_t)template_bonds(n_atoms); }
+
+extern "C" int ligdiff_template_edges(const int32_t* mol_ptr, const int64_t* edge_ptr, int32_t n_mols,
+                                      int32_t max_mol_atoms, int64_t n_edges, int64_t* edge_index, uint8_t* kind,
+                                      void* stream) {
+  if (!mol_ptr || !edge_ptr || n_mols <= 0 || max_mol_atoms <= 0 || n_edges < 0) return LIGDIFF_ERR_ARG;
+  if (n_edges == 0) return LIGDIFF_OK;
+  if (!edge_index) return LIGDIFF_ERR_ARG;
+  const int mb = template_bonds(max_mol_atoms) > 0 ? template_bonds(max_mol_atoms) : 1;
+  hipLaunchKernelGGL(k_template_edges, dim3(ceil_div((int64_t)n_mols * mb, 256)), dim3(256), 0, (hipStream_t)stream,
+                     mol_ptr, edge_ptr, n_mols, mb, n_edges, edge_index, kind);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}

@@ -34,20 +34,21 @@ __device__ __forceinline__ f32x4 philox_normal4(uint64_t seed, uint32_t step, ui
   return (f32x4){r0 * c0, r0 * s0, r1 * c1, r1 * s1};
 }
 
-__global__ void k_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, uint32_t sid, int64_t offset) {
+__global__ void k_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, uint32_t sid, int64_t offset,
+                                float scale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint64_t g = (uint64_t)(offset + i);
   const f32x4 z = philox_normal4(seed, step, sid, g >> 2);
-  out[i] = z[g & 3];
+  out[i] = z[g & 3] * scale;
 }
 
 extern "C" int ligdiff_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, uint32_t stream_id,
-                                     int64_t offset, void* stream) {
+                                     int64_t offset, float scale, void* stream) {
   if (!out || n < 0 || offset < 0) return LIGDIFF_ERR_ARG;
   if (n == 0) return LIGDIFF_OK;
   hipLaunchKernelGGL(k_philox_normal, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, seed, step,
-                     stream_id, offset);
+                     stream_id, offset, scale);
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;
 }
@@ -185,6 +186,7 @@ extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_gr
                                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!weights || !graph || !x || !pos || !betas || !alphas || !alphas_cumprod || !workspace || n_steps <= 0)
     return LIGDIFF_ERR_ARG;
+  if (use_graph && stream == nullptr) return LIGDIFF_ERR_ARG;  // the default stream cannot be captured
   // generation.py:428: guidance only when properties are given AND scale > 1
   const int guided = (properties != nullptr && guidance_scale > 1.0f) ? 1 : 0;
   SampleLayout L;
@@ -248,4 +250,90 @@ extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_gr
   (void)hipGraphExecDestroy(exec);
   (void)hipGraphDestroy(graph_h);
   return rc;
+}
+
+// ------------------------------------------------------------------ acceptance gates
+// Per-step prediction gate of the DDIM loop, generation.py:351 / :518-541: a molecule is
+// rejected once any of its predictions is NaN/Inf or exceeds 100 in magnitude.
+__global__ void k_prediction_gate(const float* __restrict__ eps_x, const float* __restrict__ eps_pos,
+                                  const int32_t* __restrict__ atom_mol, int64_t n_atoms, int32_t* __restrict__ reject) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms * (LD_A + 3)) return;
+  const int64_t nx = n_atoms * LD_A;
+  const float v = i < nx ? eps_x[i] : eps_pos[i - nx];
+  const int64_t atom = i < nx ? i / LD_A : (i - nx) / 3;
+  if (!(fabsf(v) <= 100.0f)) reject[atom_mol[atom]] = 1;  // also true for NaN
+}
+
+extern "C" int ligdiff_prediction_gate(const float* eps_x, const float* eps_pos, const int32_t* atom_mol,
+                                       int64_t n_atoms, int32_t* reject, void* stream) {
+  if (!eps_x || !eps_pos || !atom_mol || !reject || n_atoms <= 0) return LIGDIFF_ERR_ARG;
+  hipLaunchKernelGGL(k_prediction_gate, dim3(ceil_div(n_atoms * (LD_A + 3), 256)), dim3(256), 0, (hipStream_t)stream,
+                     eps_x, eps_pos, atom_mol, n_atoms, reject);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}
+
+// Final validity gates, generation.py:162-233, one wave per molecule:
+//   finite values; softmax(x) max-probability >= 0.1 for every atom; unbiased per-axis
+//   coordinate variance in [1e-6, 100]; every pairwise distance in [0.5, 20].
+// accept[m] = 1 if the molecule passes.
+__global__ __launch_bounds__(256) void k_validity_gate(const float* __restrict__ x, const float* __restrict__ pos,
+                                                       const int32_t* __restrict__ mol_ptr, int32_t B,
+                                                       int32_t* __restrict__ accept) {
+  const int lane = threadIdx.x & 63;
+  const int mol = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (mol >= B) return;
+  const int a0 = mol_ptr[mol], n = mol_ptr[mol + 1] - a0;
+  int bad = 0;
+  // atom features: finite + dominant type
+  for (int a = 0; a < n; ++a) {
+    const float* row = x + (size_t)(a0 + a) * LD_A;
+    const float v0 = lane < LD_A ? row[lane] : -INFINITY;
+    const float v1 = lane + 64 < LD_A ? row[lane + 64] : -INFINITY;
+    if ((lane < LD_A && !(fabsf(v0) <= 3.0e38f)) || (lane + 64 < LD_A && !(fabsf(v1) <= 3.0e38f))) bad = 1;
+    const float mx = wave_max(fmaxf(v0, v1));
+    const float s = wave_sum((lane < LD_A ? expf(v0 - mx) : 0.f) + (lane + 64 < LD_A ? expf(v1 - mx) : 0.f));
+    if (!(1.0f / s >= 0.1f)) bad = 1;  // max probability = exp(0) / sum
+  }
+  // coordinates: finite, variance, pairwise distances
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int a = lane; a < n; a += 64) {
+    const float* p = pos + (size_t)(a0 + a) * 3;
+    if (!(fabsf(p[0]) <= 3.0e38f) || !(fabsf(p[1]) <= 3.0e38f) || !(fabsf(p[2]) <= 3.0e38f)) bad = 1;
+    sx += p[0]; sy += p[1]; sz += p[2];
+  }
+  const float inv = 1.0f / (float)n;
+  const float mx = wave_sum(sx) * inv, my = wave_sum(sy) * inv, mz = wave_sum(sz) * inv;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  for (int a = lane; a < n; a += 64) {
+    const float* p = pos + (size_t)(a0 + a) * 3;
+    qx += (p[0] - mx) * (p[0] - mx); qy += (p[1] - my) * (p[1] - my); qz += (p[2] - mz) * (p[2] - mz);
+  }
+  const float dn = 1.0f / (float)(n - 1);  // torch.var default: unbiased (NaN for n == 1)
+  const float vx = wave_sum(qx) * dn, vy = wave_sum(qy) * dn, vz = wave_sum(qz) * dn;
+  // torch.any(var < 1e-6) / torch.any(var > 100): comparisons with NaN are false
+  if (vx < 1e-6f || vy < 1e-6f || vz < 1e-6f || vx > 100.f || vy > 100.f || vz > 100.f) bad = 1;
+  if (n > 1) {
+    for (int pr = lane; pr < n * n; pr += 64) {
+      const int i = pr / n, j = pr % n;
+      if (i == j) continue;
+      const float* p = pos + (size_t)(a0 + i) * 3;
+      const float* q = pos + (size_t)(a0 + j) * 3;
+      const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+      if (d < 0.5f || d > 20.f) bad = 1;
+    }
+  }
+  bad = __any(bad);
+  if (lane == 0) accept[mol] = bad ? 0 : 1;
+}
+
+extern "C" int ligdiff_validity_gate(const float* x, const float* pos, const int32_t* mol_ptr, int32_t n_mols,
+                                     int32_t* accept, void* stream) {
+  if (!x || !pos || !mol_ptr || !accept || n_mols <= 0) return LIGDIFF_ERR_ARG;
+  hipLaunchKernelGGL(k_validity_gate, dim3(ceil_div(n_mols, 4)), dim3(256), 0, (hipStream_t)stream, x, pos, mol_ptr,
+                     n_mols, accept);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
 }

@@ -126,10 +126,13 @@ class ScoreNetworkEngine:
         return self._ws
 
     def forward(self, graph, x, pos, t, properties=None, null_cond=False, want_props=True, save=False,
-                workspace=None):
+                workspace=None, t_index=None):
         """ligdiff_forward on the current stream.  t: [B] float tensor (or [1], applied to
-        every molecule).  Returns atom_pred, pos_pred, prop_pred (None if not wanted)."""
+        every molecule); alternatively t_index, a device int32 scalar holding the step.
+        Returns atom_pred, pos_pred, prop_pred (None if not wanted)."""
         N, B = graph.n_atoms, graph.n_mols
+        if t is None:
+            t = torch.zeros(1, device=self.device)
         if graph.max_mol_atoms > self.max_atoms:
             raise RuntimeError(f"a molecule has {graph.max_mol_atoms} atoms but the model was built with "
                                f"max_atoms={self.max_atoms} (model1.py:728)")
@@ -141,7 +144,11 @@ class ScoreNetworkEngine:
         if x.shape != (N, 119) or pos.shape != (N, 3):
             raise ValueError("x must be [N,119] and pos [N,3]")
         flags = 0
-        if t.numel() == 1 and B > 1:
+        if t_index is not None:
+            if t_index.dtype != torch.int32 or not t_index.is_cuda:
+                raise ValueError("t_index must be a device int32 tensor")
+            flags |= _lib.FWD_T_BROADCAST
+        elif t.numel() == 1 and B > 1:
             flags |= _lib.FWD_T_BROADCAST
         elif t.numel() < B:
             raise ValueError("t needs one value per molecule")
@@ -167,9 +174,108 @@ class ScoreNetworkEngine:
         pos_pred = torch.empty(N, 3, dtype=torch.float32, device=self.device)
         prop_pred = torch.empty(B, 15, dtype=torch.float32, device=self.device) if want_props else None
         with torch.cuda.device(self.device):
-            rc = self.lib.ligdiff_forward(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(t), None,
+            rc = self.lib.ligdiff_forward(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(t), _ptr(t_index),
                                           _ptr(properties) if (properties is not None and not null_cond) else None,
                                           flags, _ptr(atom_pred), _ptr(pos_pred), _ptr(prop_pred), _ptr(ws),
                                           ws.numel(), _stream())
         check(rc, "ligdiff_forward")
         return atom_pred, pos_pred, prop_pred
+
+    # ------------------------------------------------------------------ sampler entry points
+    def step_args(self, model, x, pos, eps_x, eps_pos, eps_xu=None, eps_pu=None, guidance_scale=1.0,
+                  temperature=1.0, t_index=None, noise_x=None, noise_pos=None, seed=0, atom_offset=0):
+        a = _lib.StepArgs()
+        a.x, a.pos, a.eps_x, a.eps_pos = x.data_ptr(), pos.data_ptr(), eps_x.data_ptr(), eps_pos.data_ptr()
+        a.eps_x_uncond = eps_xu.data_ptr() if eps_xu is not None else None
+        a.eps_pos_uncond = eps_pu.data_ptr() if eps_pu is not None else None
+        a.guidance_scale, a.temperature = float(guidance_scale), float(temperature)
+        a.betas, a.alphas = model.betas.data_ptr(), model.alphas.data_ptr()
+        a.alphas_cumprod = model.alphas_cumprod.data_ptr()
+        a.t_index_dev = t_index.data_ptr() if t_index is not None else None
+        a.noise_x = noise_x.data_ptr() if noise_x is not None else None
+        a.noise_pos = noise_pos.data_ptr() if noise_pos is not None else None
+        a.seed, a.atom_offset, a.n_atoms = int(seed), int(atom_offset), x.shape[0]
+        return a
+
+    def ddpm_step(self, args):
+        with torch.cuda.device(self.device):
+            check(self.lib.ligdiff_ddpm_step(C.byref(args), _stream()), "ligdiff_ddpm_step")
+
+    def ddim_step(self, args, t_cur, t_next):
+        with torch.cuda.device(self.device):
+            check(self.lib.ligdiff_ddim_step(C.byref(args), int(t_cur), int(t_next), _stream()), "ligdiff_ddim_step")
+
+    def ddpm_sample(self, model, graph, x, pos, properties=None, guidance_scale=1.0, temperature=1.0,
+                    n_steps=None, seed=0, atom_offset=0, use_graph=True):
+        """Whole reverse loop in the library (hipGraph replay); x / pos updated in place."""
+        n_steps = model.timesteps if n_steps is None else n_steps
+        guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
+        nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, guided)
+        ws = self.workspace(nbytes)
+        if properties is not None:
+            properties = properties.contiguous().float()
+            if properties.shape != (graph.n_mols, 15):
+                raise ValueError("properties must be [B,15]")
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            # stream capture is not possible on the legacy default stream: hop to a side stream
+            run_on = cur
+            if use_graph and cur.cuda_stream == 0:
+                if getattr(self, "_side", None) is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                run_on = self._side
+                run_on.wait_stream(cur)
+            with torch.cuda.stream(run_on):
+                rc = self.lib.ligdiff_ddpm_sample(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
+                                                  float(guidance_scale), float(temperature), _ptr(model.betas),
+                                                  _ptr(model.alphas), _ptr(model.alphas_cumprod), int(n_steps),
+                                                  int(seed), int(atom_offset), 1 if use_graph else 0, _ptr(ws),
+                                                  ws.numel(), _stream())
+            if run_on is not cur:
+                cur.wait_stream(run_on)
+        check(rc, "ligdiff_ddpm_sample")
+
+    def philox_normal(self, n, seed, step, stream_id, offset=0, scale=1.0):
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.ligdiff_philox_normal(_ptr(out), n, int(seed), int(step), int(stream_id), int(offset),
+                                                 float(scale), _stream()), "ligdiff_philox_normal")
+        return out
+
+    def validity_gate(self, x, pos, mol_ptr, n_mols):
+        accept = torch.empty(n_mols, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.ligdiff_validity_gate(_ptr(x), _ptr(pos), _ptr(mol_ptr), n_mols, _ptr(accept), _stream()),
+                  "ligdiff_validity_gate")
+        return accept
+
+    def prediction_gate(self, eps_x, eps_pos, graph, reject):
+        with torch.cuda.device(self.device):
+            check(self.lib.ligdiff_prediction_gate(_ptr(eps_x), _ptr(eps_pos), _ptr(graph.atom_mol), graph.n_atoms,
+                                                   _ptr(reject), _stream()), "ligdiff_prediction_gate")
+
+
+def template_graph(sizes, device):
+    """Batch of molecules with the generator's bond template (generation.py:562-668), built
+    on device.  Returns (PackedGraph, edge_index [2,E] int64, kind [E] uint8)."""
+    lib = _lib.load()
+    sizes = [int(n) for n in sizes]
+    if min(sizes) < 1:
+        raise ValueError("molecule sizes must be >= 1")
+    if min(sizes) < 2:
+        raise ValueError("a one-atom molecule has no bonds: outside the generator's supported domain")
+    B = len(sizes)
+    counts = [lib.ligdiff_template_edge_count(n) for n in sizes]
+    mol_ptr = torch.zeros(B + 1, dtype=torch.int32)
+    mol_ptr[1:] = torch.tensor(sizes, dtype=torch.int64).cumsum(0).to(torch.int32)
+    edge_ptr = torch.zeros(B + 1, dtype=torch.int64)
+    edge_ptr[1:] = torch.tensor(counts, dtype=torch.int64).cumsum(0)
+    E = int(edge_ptr[-1])
+    mol_ptr_d, edge_ptr_d = mol_ptr.to(device), edge_ptr.to(device)
+    edge_index = torch.empty(2, E, dtype=torch.int64, device=device)
+    kind = torch.empty(E, dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        check(lib.ligdiff_template_edges(_ptr(mol_ptr_d), _ptr(edge_ptr_d), B, max(sizes), E, _ptr(edge_index),
+                                         _ptr(kind), _stream()), "ligdiff_template_edges")
+    batch = torch.repeat_interleave(torch.arange(B, dtype=torch.int64), torch.tensor(sizes)).to(device)
+    return PackedGraph(edge_index, batch, num_mols=B), edge_index, kind

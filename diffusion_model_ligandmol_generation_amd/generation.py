@@ -1,0 +1,243 @@
+"""Drop-in generator: the reference's ResearchValidatedGenerator call surface over the HIP
+library, with molecules sampled as ONE packed batch instead of one at a time.
+
+Mirrors generation.py:18-680.  What differs on purpose:
+* molecules of a request are packed into CSR batches and run through the reverse loop
+  together (the reference's loop at generation.py:67 has no cross-molecule state, so the
+  result per molecule is the same function of its own noise);
+* Gaussian noise comes from an in-kernel Philox stream keyed by (seed, step, global atom
+  index) unless the caller injects its own draws;
+* failures raise; only a REJECTED sample (validity gates) yields ``None`` as in the
+  reference.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .engine import template_graph
+
+_SINGLE = [1.0, 0.0, 0.0, 0.0, 0.0]
+_AROMATIC = [0.0, 0.0, 0.0, 1.0, 1.0]
+
+
+def _add_missing_attributes_to_model(model):
+    """generation.py:671-680: DDPM posterior variance buffer (not used by the samplers)."""
+    if not hasattr(model, "posterior_variance"):
+        prev = F.pad(model.alphas_cumprod[:-1], (1, 0), value=1.0)
+        model.register_buffer("posterior_variance", model.betas * (1.0 - prev) / (1.0 - model.alphas_cumprod))
+
+
+class ResearchValidatedGenerator:
+    def __init__(self, model, use_ema=True):
+        if not next(model.parameters()).is_cuda:
+            if not torch.cuda.is_available():
+                raise RuntimeError("ResearchValidatedGenerator needs a HIP device; there is no CPU path")
+            model = model.cuda()
+        self.model = model
+        self.use_ema = use_ema
+        self.device = next(model.parameters()).device
+        self.batch_atoms = 32768          # atoms per packed sampling batch
+        self.seed = 0
+        self.last_stats = {}
+        _add_missing_attributes_to_model(self.model)
+
+    # ------------------------------------------------------------------ public API (reference names)
+    def generate_with_research_protocols(self, num_molecules=1000, target_properties=None, atom_range=(10, 40),
+                                         guidance_scale=2.0, num_sampling_steps=100, temperature=1.0,
+                                         use_ddim=True):
+        """generation.py:38-124.  Returns the list of accepted molecules (dicts with the
+        reference's keys).  ``self.last_stats`` reports attempted / accepted counts."""
+        self.model.eval()
+        sizes = [self._sample_realistic_molecule_size(atom_range) for _ in range(num_molecules)]
+        results, accepted_flags = self.sample_many(sizes, target_properties, guidance_scale, temperature,
+                                                   use_ddim, num_sampling_steps)
+        out = []
+        tp = self._extract_target_properties(target_properties)
+        for i, ((x, pos), ok) in enumerate(zip(results, accepted_flags)):
+            if not ok:
+                continue
+            out.append({"atom_features": x, "positions": pos, "num_atoms": sizes[i], "generation_id": i,
+                        "target_properties": tp, "generated_by_model": True, "research_compliant": True})
+        n_ok = len(out)
+        self.last_stats = {"attempted": num_molecules, "accepted": n_ok,
+                           "success_rate": n_ok / max(1, num_molecules)}
+        return out
+
+    def sample_many(self, sizes, target_properties=None, guidance_scale=2.0, temperature=1.0, use_ddim=False,
+                    num_steps=100, seed=None):
+        """Samples every size in ``sizes``; returns ([(x_np, pos_np)], [accepted bool])."""
+        seed = self.seed if seed is None else seed
+        results, flags = [], []
+        i, atom_offset = 0, 0
+        with torch.no_grad():
+            while i < len(sizes):
+                j, tot = i, 0
+                while j < len(sizes) and (tot + sizes[j] <= self.batch_atoms or j == i):
+                    tot += sizes[j]
+                    j += 1
+                chunk = sizes[i:j]
+                x, pos, graph, rejected = self.sample_batch(chunk, target_properties, guidance_scale, temperature,
+                                                            use_ddim, num_steps, seed=seed, atom_offset=atom_offset)
+                accept = self.model.engine().validity_gate(x, pos, graph.mol_ptr, graph.n_mols)
+                accept = (accept.bool() & ~rejected.bool()).cpu().numpy()
+                xh, ph = x.cpu().numpy(), pos.cpu().numpy()       # generation.py:246
+                mp = graph.mol_ptr.cpu().numpy()
+                for m in range(len(chunk)):
+                    results.append((xh[mp[m]:mp[m + 1]], ph[mp[m]:mp[m + 1]]))
+                    flags.append(bool(accept[m]))
+                atom_offset += tot
+                i = j
+        return results, flags
+
+    def sample_batch(self, sizes, target_properties=None, guidance_scale=2.0, temperature=1.0, use_ddim=False,
+                     num_steps=100, seed=0, atom_offset=0, noise=None, use_graph=True, trace=None):
+        """One packed batch through the reverse loop.  Returns (x, pos, graph, rejected[B]).
+
+        noise: optional callable ``noise(kind, t, shape) -> device tensor`` with kind in
+        {"x0", "pos0", "x", "pos"}; when given, every Gaussian draw is taken from it (parity
+        runs) and the loop is driven step by step from the host.
+        trace: optional callable ``trace(t, x, pos)`` seeing the state that enters step t.
+        """
+        model, eng, dev = self.model, self.model.engine(), self.device
+        graph, _, _ = template_graph(sizes, dev)
+        N, B = graph.n_atoms, graph.n_mols
+        props = self._prepare_pilot_properties(target_properties)
+        if props is not None:
+            props = props.to(dev).float()
+            if props.shape[0] == 1 and B > 1:
+                props = props.repeat(B, 1)
+        guided = props is not None and guidance_scale > 1.0                     # generation.py:428
+        T = model.timesteps
+        init_step = 0xFFFFFFFF
+        if noise is None:
+            x = eng.philox_normal(N * 119, seed, init_step, 0, atom_offset * 119, temperature).view(N, 119)
+            pos = eng.philox_normal(N * 3, seed, init_step, 1, atom_offset * 3, temperature).view(N, 3)
+        else:
+            x = (noise("x0", T, (N, 119)) * temperature).contiguous()
+            pos = (noise("pos0", T, (N, 3)) * temperature).contiguous()
+        rejected = torch.zeros(B, dtype=torch.int32, device=dev)
+        if not use_ddim and noise is None and trace is None:
+            eng.ddpm_sample(model, graph, x, pos, props, guidance_scale, temperature, T, seed, atom_offset, use_graph)
+            return x, pos, graph, rejected
+        t_index = torch.zeros(1, dtype=torch.int32, device=dev)
+        if use_ddim:
+            steps = torch.linspace(T - 1, 0, num_steps, dtype=torch.long).tolist()  # generation.py:305
+        else:
+            steps = list(range(T - 1, -1, -1))                                    # generation.py:422
+        for i, t in enumerate(steps):
+            if trace is not None:
+                trace(t, x, pos)
+            t_index.fill_(t)
+            ex, ep, _ = eng.forward(graph, x, pos, None, props, want_props=False, t_index=t_index)
+            exu = epu = None
+            if guided:
+                exu, epu, _ = eng.forward(graph, x, pos, None, None, want_props=False, t_index=t_index)
+            nx = npos = None
+            if not use_ddim and noise is not None and t > 1:
+                nx, npos = noise("x", t, (N, 119)).contiguous(), noise("pos", t, (N, 3)).contiguous()
+            args = eng.step_args(model, x, pos, ex, ep, exu, epu, guidance_scale, temperature, t_index, nx, npos,
+                                 seed, atom_offset)
+            if use_ddim:
+                eng.prediction_gate(ex if not guided else exu + guidance_scale * (ex - exu),
+                                    ep if not guided else epu + guidance_scale * (ep - epu), graph, rejected)
+                eng.ddim_step(args, t, steps[i + 1] if i + 1 < len(steps) else -1)
+            else:
+                eng.ddpm_step(args)
+        return x, pos, graph, rejected
+
+    def ddpm_sampling_fixed(self, num_atoms, target_properties, guidance_scale, temperature):
+        """generation.py:393-494 for one molecule: (x, pos) tensors, or None if rejected."""
+        return self._single(num_atoms, target_properties, guidance_scale, temperature, False, None)
+
+    def ddim_sampling_fixed(self, num_atoms, target_properties, num_steps, guidance_scale, temperature):
+        """generation.py:279-391 for one molecule."""
+        return self._single(num_atoms, target_properties, guidance_scale, temperature, True, num_steps)
+
+    def _single(self, num_atoms, target_properties, guidance_scale, temperature, use_ddim, num_steps):
+        self.model.eval()
+        with torch.no_grad():
+            x, pos, graph, rejected = self.sample_batch([num_atoms], target_properties, guidance_scale, temperature,
+                                                        use_ddim, num_steps or 0, seed=self.seed)
+            self.seed += 1
+            if int(rejected[0]) or not self._validate_final_molecule(x, pos, num_atoms):
+                return None
+        return x, pos
+
+    # ------------------------------------------------------------------ host-side helpers
+    def _sample_realistic_molecule_size(self, atom_range):
+        """generation.py:126-140 (numpy global RNG, as in the reference)."""
+        lo, hi = atom_range
+        if lo <= 20 <= hi:
+            top = min(31, hi)
+            return int(np.random.choice(range(15, top), p=self._get_drug_size_probabilities(15, top)))
+        return int(np.random.randint(lo, hi))
+
+    def _get_drug_size_probabilities(self, min_size, max_size):
+        """generation.py:142-160."""
+        w = [0.15 if 18 <= s <= 25 else (0.1 if 15 <= s <= 30 else 0.05) for s in range(min_size, max_size)]
+        tot = sum(w)
+        return [v / tot for v in w]
+
+    def _validate_research_compliance(self, atom_features, positions, num_atoms):
+        """generation.py:162-233 through the device gate kernel."""
+        if atom_features is None or positions is None:
+            return False
+        if not torch.is_tensor(atom_features) or not torch.is_tensor(positions):
+            return False
+        if atom_features.shape != (num_atoms, 119) or positions.shape != (num_atoms, 3):
+            return False
+        mol_ptr = torch.tensor([0, num_atoms], dtype=torch.int32, device=self.device)
+        acc = self.model.engine().validity_gate(atom_features.to(self.device).float().contiguous(),
+                                                positions.to(self.device).float().contiguous(), mol_ptr, 1)
+        return bool(int(acc[0]))
+
+    def _validate_final_molecule(self, x, pos, num_atoms):
+        """generation.py:543-560."""
+        if x is None or pos is None or x.shape[0] != num_atoms or pos.shape[0] != num_atoms:
+            return False
+        return self._validate_research_compliance(x, pos, num_atoms)
+
+    def _prepare_pilot_properties(self, target_properties):
+        """generation.py:496-516; dict-valued properties make the reference's model call
+        fail (model1.py:337) and are rejected here."""
+        if target_properties is None:
+            return None
+        if not torch.is_tensor(target_properties):
+            raise TypeError("target_properties must be a tensor of 15 values (or [B,15]) or None")
+        if target_properties.dim() == 1:
+            target_properties = target_properties.unsqueeze(0)
+        if torch.isnan(target_properties).any() or torch.isinf(target_properties).any():
+            return None
+        return target_properties
+
+    def _extract_target_properties(self, target_properties):
+        """generation.py:263-277."""
+        if target_properties is None:
+            return None
+        if torch.is_tensor(target_properties):
+            if torch.isnan(target_properties).any() or torch.isinf(target_properties).any():
+                return None
+            return target_properties.cpu().numpy()
+        return target_properties
+
+    def create_research_connectivity_fixed(self, num_atoms):
+        """generation.py:562-668 as host lists (edge_indices, edge_features); the batched
+        samplers build the same edges on device (ligdiff_template_edges)."""
+        n = num_atoms
+        if n <= 5:
+            bonds = [(i, i + 1, _SINGLE) for i in range(n - 1)]
+        else:
+            bonds = [(i, (i + 1) % 6, _AROMATIC) for i in range(6)]
+            if n <= 15:
+                bonds += [((2 * k) % 6, 6 + k, _SINGLE) for k in range(n - 6)]
+            else:
+                bonds += [(6 + i, 6 + (i + 1) % 5, _AROMATIC) for i in range(5)]
+                bonds += [(1, 6, _AROMATIC), (2, 10, _AROMATIC)]
+                bonds += [(k % 11, 11 + k, _SINGLE) for k in range(n - 11)]
+        edge_indices, edge_features = [], []
+        for a, b, f in bonds:
+            edge_indices.extend([[a, b], [b, a]])
+            edge_features.extend([list(f), list(f)])
+        if len(edge_indices) > n * 8:
+            return None
+        return edge_indices, edge_features

@@ -159,7 +159,9 @@ int ligdiff_ddim_step(const ligdiff_step_args* args, int32_t t_cur, int32_t t_ne
  * Whole 1000-step DDPM loop of generation.py:422-484 for a packed batch of molecules:
  * captures one reverse step (forward [+ unconditional forward] + fused update) into a
  * hipGraph on `stream` and replays it n_steps times.  x / pos hold the initial noise on
- * entry and the sample on return.  properties NULL -> unguided.
+ * entry and the sample on return.  properties NULL -> unguided.  use_graph != 0 needs a
+ * non-default stream (the legacy default stream cannot be captured) and returns after
+ * the stream has drained; use_graph == 0 only enqueues.
  */
 int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
                         const float* properties, float guidance_scale, float temperature,
@@ -171,7 +173,36 @@ size_t ligdiff_ddpm_sample_workspace_bytes(int64_t n_atoms, int64_t n_edges, int
 /* Fills out[n] with the N(0,1) draws the in-kernel Philox stream yields for
  * (seed, step, global element index offset..offset+n): lets a host reproduce a run. */
 int ligdiff_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, uint32_t stream_id,
-                          int64_t offset, void* stream);
+                          int64_t offset, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Generator-side helpers.
+ * ------------------------------------------------------------------------------- */
+
+/* Directed edges the bond template of generation.py:562-668 gives an n-atom molecule:
+ * 0 (n<=1), 2(n-1) (n<=5), 2n (n<=15), 2n+4 (n>=16). */
+int64_t ligdiff_template_edge_count(int32_t n_atoms);
+
+/* Replaces create_research_connectivity_fixed (generation.py:562-668) for a whole batch:
+ * writes edge_index [2,E] int64 (atom indices already offset by each molecule's first atom,
+ * edges in the reference's order) and, if kind != NULL, kind[E] = 1 for ring/fusion bonds
+ * (feature [0,0,0,1,1]) and 0 for chain/substituent bonds ([1,0,0,0,0]).
+ * mol_ptr [B+1] int32 atoms, edge_ptr [B+1] int64 exclusive prefix of the per-molecule
+ * edge counts, n_edges = edge_ptr[B].  Integer, bit-exact. */
+int ligdiff_template_edges(const int32_t* mol_ptr, const int64_t* edge_ptr, int32_t n_mols,
+                           int32_t max_mol_atoms, int64_t n_edges, int64_t* edge_index, uint8_t* kind,
+                           void* stream);
+
+/* generation.py:518-541 per molecule: reject[m] is SET to 1 (never cleared) when any
+ * prediction of molecule m is NaN/Inf or above 100 in magnitude. */
+int ligdiff_prediction_gate(const float* eps_x, const float* eps_pos, const int32_t* atom_mol,
+                            int64_t n_atoms, int32_t* reject, void* stream);
+
+/* generation.py:162-233 per molecule: accept[m] = 1 iff finite, softmax max-probability
+ * >= 0.1 for every atom, per-axis coordinate variance in [1e-6, 100] and every pairwise
+ * distance in [0.5, 20]. */
+int ligdiff_validity_gate(const float* x, const float* pos, const int32_t* mol_ptr, int32_t n_mols,
+                          int32_t* accept, void* stream);
 
 #ifdef __cplusplus
 }
