@@ -47,6 +47,9 @@ SIGNATURES = {
     "ligdiff_forward": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
+    "ligdiff_forward_timed": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_float)]),
     "ligdiff_ddpm_step": (C.c_int, [C.POINTER(StepArgs), C.c_void_p]),
     "ligdiff_ddim_step": (C.c_int, [C.POINTER(StepArgs), C.c_int32, C.c_int32, C.c_void_p]),
     "ligdiff_ddpm_sample_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int]),

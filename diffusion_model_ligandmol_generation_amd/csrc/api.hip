@@ -56,3 +56,39 @@ extern "C" int ligdiff_forward(const float* const* weights, const ligdiff_graph*
   return run_forward(weights, graph, x, pos, t, t_index_dev, properties, flags, atom_pred, pos_pred, prop_pred,
                      (char*)workspace, (hipStream_t)stream);
 }
+
+// Measurement hook for bench.py: runs `reps` forwards on `stream` and returns the mean
+// duration (ms, HIP events recorded on that stream) of the single launch labelled
+// `label` ("dit1.ffn_up", "e3_1.aggregate", ...).  Synchronises the stream.
+extern "C" int ligdiff_forward_timed(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                                     const float* pos, const float* t, const int32_t* t_index_dev,
+                                     const float* properties, int flags, float* atom_pred, float* pos_pred,
+                                     float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
+                                     const char* label, int32_t reps, float* mean_ms_host) {
+  int rc = check_graph(graph);
+  if (rc) return rc;
+  if (!weights || !x || !pos || (!t && !t_index_dev) || !atom_pred || !pos_pred || !workspace || !label ||
+      reps <= 0 || !mean_ms_host)
+    return LIGDIFF_ERR_ARG;
+  if (workspace_bytes < ligdiff_forward_workspace_bytes(graph->n_atoms, graph->n_edges, graph->n_mols, flags))
+    return LIGDIFF_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  FwdProbe p;
+  p.label = label; p.hits = 0;
+  if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return LIGDIFF_ERR_LAUNCH;
+  double total = 0.0;
+  for (int i = 0; i < reps && rc == 0; ++i) {
+    p.hits = 0;
+    rc = run_forward(weights, graph, x, pos, t, t_index_dev, properties, flags, atom_pred, pos_pred, prop_pred,
+                     (char*)workspace, s, &p);
+    if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
+    if (rc == 0 && p.hits != 1) rc = LIGDIFF_ERR_ARG;  // unknown label
+    float ms = 0.f;
+    if (rc == 0 && hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
+    total += ms;
+  }
+  (void)hipEventDestroy(p.e0);
+  (void)hipEventDestroy(p.e1);
+  *mean_ms_host = (float)(total / reps);
+  return rc;
+}

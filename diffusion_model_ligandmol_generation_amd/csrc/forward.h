@@ -21,6 +21,10 @@ struct FwdLayout {
 };
 void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags);
 
+// Measurement hook: the launch whose label equals `label` is bracketed by e0 / e1.
+struct FwdProbe { const char* label; hipEvent_t e0, e1; int hits; };
+
 int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
                 const float* t, const int32_t* t_index_dev, const float* properties, int flags,
-                float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s);
+                float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s,
+                FwdProbe* probe = nullptr);

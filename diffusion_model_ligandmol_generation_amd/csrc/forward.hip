@@ -156,8 +156,20 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
 // ------------------------------------------------------------------ the forward pass
 int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
                 const float* t, const int32_t* t_index_dev, const float* properties, int flags,
-                float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s) {
+                float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s, FwdProbe* probe) {
   const int N = (int)g->n_atoms, E = (int)g->n_edges, B = g->n_mols;
+  // PB(label) ... PE(): brackets one launch with the probe's events when its label matches
+  char lbl[48];
+  bool hit = false;
+  auto PB = [&](const char* fmt, int l = 0) {
+    if (probe == nullptr) return;
+    snprintf(lbl, sizeof lbl, fmt, l);
+    hit = strcmp(lbl, probe->label) == 0;
+    if (hit) (void)hipEventRecord(probe->e0, s);
+  };
+  auto PE = [&]() {
+    if (hit) { (void)hipEventRecord(probe->e1, s); probe->hits++; hit = false; }
+  };
   FwdLayout L;
   fwd_layout(&L, N, E, B, flags);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
@@ -166,12 +178,21 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   const int mstride = (flags & LIGDIFF_FWD_T_BROADCAST) ? 0 : 1536;
 
   // --- time embedding (model1.py:705-706) and adaLN parameters (model1.py:288)
+  PB("time.fourier");
   hipLaunchKernelGGL(k_fourier, dim3(Bt), dim3(128), 0, s, t, t_index_dev, w[W_TIME_FREQS], F(L.tf));
+  PE();
+  PB("time.mlp0");
   gemm_bias_act<ACT_GELU, false>(F(L.tf), 256, Bt, 256, w[W_T0_W], 256, w[W_T0_B], 2, F(L.t1), 512, nullptr, s);
+  PE();
+  PB("time.mlp2");
   gemm_bias_act<ACT_NONE, true>(F(L.t1), 512, Bt, 512, w[W_T2_W], 512, w[W_T2_B], 1, F(L.temb), 256, F(L.stemb), s);
-  for (int l = 0; l < 3; ++l)
+  PE();
+  for (int l = 0; l < 3; ++l) {
+    PB("dit%d.adaln", l);
     gemm_bias_act<ACT_NONE, false>(F(L.stemb), 256, Bt, 256, w[W_DIT(l, DIT_ADA_W)], 256, w[W_DIT(l, DIT_ADA_B)], 6,
                                    F(L.mod[l]), 1536, nullptr, s);
+    PE();
+  }
 
   // --- PILOT conditioning (model1.py:714-718, :335-359)
   const float* pemb = nullptr;
@@ -202,7 +223,9 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     e.pos = pos; e.Wp = w[W_POS_W]; e.bp = w[W_POS_B]; e.gp = w[W_POS_G]; e.bep = w[W_POS_BE];
     e.temb = F(L.temb); e.temb_stride = tstride; e.pemb = pemb; e.pemb_stride = pstride;
     e.atom_mol = g->atom_mol; e.H = F(L.h0);
+    PB("embed");
     launch_gemm<8, W_SCALAR>(gc, al, e, 1, s);
+    PE();
   }
 
   // --- E(3) message-passing layers (model1.py:721-725, :86-114)
@@ -219,19 +242,25 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       EpiBiasAct<8, ACT_NONE, false> e;
       memset(&e, 0, sizeof e);
       e.M = N; e.n_valid = 256; e.col_block = 256; e.C = F(L.P[l]); e.ldc = 512; e.alpha = 1.0f;
+      PB("e3_%d.node_proj", l);
       launch_gemm<8, W_ALIGNED>(gc, al, e, 2, s);
+      PE();
     }
     if (E > 0) {
+      PB("e3_%d.edge_geom", l);
       hipLaunchKernelGGL(k_edge_geom, dim3(ceil_div(E, 256)), dim3(256), 0, s, pos_l, g->src, g->dst,
                          w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB0_B)], w[W_E3(l, E3_RB2_W)], w[W_E3(l, E3_RB2_B)],
                          F(L.rel[l]), F(L.rbf[l]), (float*)nullptr, E);
+      PE();
       {  // a1 = SiLU(Pa[src] + Pb[dst] + Wc rbf + b1)
         GemmCore gc;
         memset(&gc, 0, sizeof gc);
         gc.M = E; gc.K = 32; gc.n_valid = 256; gc.ldw = 544; gc.W[0] = w[W_E3(l, E3_EN0_W)] + 512;
         ALoadPlain al{F(L.rbf[l]), 32, E, 32};
         EpiEdgePre<false> e{E, w[W_E3(l, E3_EN0_B)], F(L.P[l]), g->src, g->dst, F(L.a1[l]), nullptr};
+        PB("e3_%d.edge_pre", l);
         launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+        PE();
       }
       {  // msg = LN(a1 W2^T + b2)
         GemmCore gc = core_blocks(E, 256, 256, w[W_E3(l, E3_EN2_W)], 256, 1, 256);
@@ -240,19 +269,25 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         memset(&e, 0, sizeof e);
         e.M = E; e.bias[0] = w[W_E3(l, E3_EN2_B)]; e.gamma[0] = w[W_E3(l, E3_EN3_G)]; e.beta[0] = w[W_E3(l, E3_EN3_B)];
         e.eps = 1e-5f; e.C = F(L.msg[l]); e.ldc = 256;
+        PB("e3_%d.edge_mlp2", l);
         launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+        PE();
       }
       {  // wrel = rel * tanh(w2 . SiLU(msg Wc1^T + b) + b2)
         GemmCore gc = core_blocks(E, 256, 128, w[W_E3(l, E3_CN0_W)], 256, 1, 128);
         ALoadPlain al{F(L.msg[l]), 256, E, 256};
         EpiCoord<false> e{E, w[W_E3(l, E3_CN0_B)], w[W_E3(l, E3_CN2_W)], w[W_E3(l, E3_CN2_B)],
                           F(L.rel[l]), F(L.wrel[l]), nullptr, nullptr};
+        PB("e3_%d.coord", l);
         launch_gemm<4, W_ALIGNED>(gc, al, e, 1, s);
+        PE();
       }
     }
+    PB("e3_%d.aggregate", l);
     hipLaunchKernelGGL(k_aggregate, dim3(ceil_div(N, 4)), dim3(256), 0, s, F(L.msg[l]), F(L.wrel[l]), g->dst_ptr,
                        g->src_ptr, g->src_slot, pos, F(L.pos_upd), F(L.pos_cur), F(L.agg[l]), (float*)nullptr, N,
                        l == 0 ? 1 : 0);
+    PE();
     {  // hid = SiLU([h | agg] Wn1^T + b)
       GemmCore gc = core_blocks(N, 512, 256, w[W_E3(l, E3_NN0_W)], 512, 1, 256);
       ALoadConcat al{h_in, F(L.agg[l]), 256, 256, 256, N, 512};
@@ -260,7 +295,9 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       memset(&e, 0, sizeof e);
       e.M = N; e.n_valid = 256; e.col_block = 256; e.bias[0] = w[W_E3(l, E3_NN0_B)]; e.C = F(L.hid[l]); e.ldc = 256;
       e.alpha = 1.0f;
+      PB("e3_%d.node_mlp1", l);
       launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      PE();
     }
     {  // h = h + LN(hid Wn2^T + b)
       GemmCore gc = core_blocks(N, 256, 256, w[W_E3(l, E3_NN2_W)], 256, 1, 256);
@@ -269,7 +306,9 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       memset(&e, 0, sizeof e);
       e.M = N; e.bias[0] = w[W_E3(l, E3_NN2_B)]; e.gamma[0] = w[W_E3(l, E3_NN3_G)]; e.beta[0] = w[W_E3(l, E3_NN3_B)];
       e.eps = 1e-5f; e.C = F(L.h_e3[l]); e.ldc = 256; e.resid = h_in; e.ldr = 256;
+      PB("e3_%d.node_mlp2", l);
       launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      PE();
     }
     h_in = F(L.h_e3[l]);
   }
@@ -277,41 +316,57 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   // --- adaLN attention layers over each molecule's own atoms (model1.py:728-738, :279-302)
   const int max_n = g->max_mol_atoms;
   const float* x_in = h_in;
+  PB("dit0.ln_mod");
   hipLaunchKernelGGL(k_ln_mod, dim3(ceil_div(N, 4)), dim3(256), 0, s, x_in, F(L.mod[0]), mstride, 0, 256,
                      g->atom_mol, F(L.xn1[0]), N);
+  PE();
   for (int l = 0; l < 3; ++l) {
+    PB("dit%d.qkv", l);
     gemm_bias_act<ACT_NONE, false>(F(L.xn1[l]), 256, N, 256, w[W_DIT(l, DIT_INP_W)], 256, w[W_DIT(l, DIT_INP_B)], 3,
                                    F(L.qkv[l]), 768, nullptr, s);
+    PE();
     if (max_n <= 32) {
       const size_t lds = (size_t)4 * 2 * 32 * 64 * 4;
+      PB("dit%d.attention", l);
       hipLaunchKernelGGL(k_attention<32>, dim3(B), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]),
                          (float*)nullptr, 32);
+      PE();
     } else {
       const int mn = max_n <= 64 ? 64 : 128;
       const size_t lds = (size_t)4 * mn * 64 * 4;
+      PB("dit%d.attention", l);
       hipLaunchKernelGGL(k_attention<64>, dim3(B * 2), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]),
                          (float*)nullptr, mn);
+      PE();
     }
     {  // x1 = x + gate_msa * (att Wo^T + b);  xn2 = LN(x1)(1+scale_mlp)+shift_mlp
       GemmCore gc = core_blocks(N, 256, 256, w[W_DIT(l, DIT_OUT_W)], 256, 1, 256);
       ALoadPlain al{F(L.att[l]), 256, N, 256};
       EpiGate<true> e{N, w[W_DIT(l, DIT_OUT_B)], x_in, F(L.mod[l]), mstride, 512, F(L.mod[l]), 768, 1024,
                       g->atom_mol, F(L.x1[l]), F(L.xn2[l])};
+      PB("dit%d.out_proj", l);
       launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      PE();
     }
+    PB("dit%d.ffn_up", l);
     gemm_bias_act<ACT_GELU, false>(F(L.xn2[l]), 256, N, 256, w[W_DIT(l, DIT_FF0_W)], 256, w[W_DIT(l, DIT_FF0_B)], 4,
                                    F(L.ffh[l]), 1024, nullptr, s);
+    PE();
     {  // x2 = x1 + gate_mlp * (ffh W3^T + b); next layer's xn1 fused
       GemmCore gc = core_blocks(N, 1024, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1, 256);
       ALoadPlain al{F(L.ffh[l]), 1024, N, 1024};
       if (l < 2) {
         EpiGate<true> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l + 1]), 0, 256,
                         g->atom_mol, F(L.x2[l]), F(L.xn1[l + 1])};
+        PB("dit%d.ffn_down", l);
         launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+        PE();
       } else {
         EpiGate<false> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l]), 0, 256,
                          g->atom_mol, F(L.x2[l]), nullptr};
+        PB("dit%d.ffn_down", l);
         launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+        PE();
       }
     }
     x_in = F(L.x2[l]);
@@ -330,7 +385,9 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     for (int hd = 0; hd < 2; ++hd) {
       e.bias[hd] = w[W_HEAD(hd, HEAD_B0)]; e.gamma[hd] = w[W_HEAD(hd, HEAD_G)]; e.beta[hd] = w[W_HEAD(hd, HEAD_BE)];
     }
+    PB("head.hidden");
     launch_gemm<8, W_ALIGNED>(gc, al, e, 2, s);
+    PE();
   }
   {  // atom_pred = y_atom W3^T + b   (119 outputs)
     GemmCore gc = core_blocks(N, 256, LD_A, w[W_HEAD(0, HEAD_W3)], 256, 1, 128);
@@ -339,10 +396,14 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     memset(&e, 0, sizeof e);
     e.M = N; e.n_valid = LD_A; e.col_block = 0; e.bias[0] = w[W_HEAD(0, HEAD_B3)]; e.C = atom_pred; e.ldc = LD_A;
     e.alpha = 1.0f;
+    PB("head.atom");
     launch_gemm<4, W_ALIGNED>(gc, al, e, 1, s);
+    PE();
   }
+  PB("head.pos");
   hipLaunchKernelGGL(k_head_small<3>, dim3(ceil_div(N, 4)), dim3(256), 0, s, F(L.yh), 512, 256, w[W_HEAD(1, HEAD_W3)],
                      w[W_HEAD(1, HEAD_B3)], F(L.pos_upd), pos_pred, N);
+  PE();
   if (!(flags & LIGDIFF_FWD_SKIP_PROP_HEAD)) {
     if (prop_pred == nullptr) return LIGDIFF_ERR_ARG;
     hipLaunchKernelGGL(k_mean_pool, dim3(ceil_div(B, 4)), dim3(256), 0, s, x_in, g->mol_ptr, F(L.pooled), B);

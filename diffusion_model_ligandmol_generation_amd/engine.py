@@ -181,6 +181,22 @@ class ScoreNetworkEngine:
         check(rc, "ligdiff_forward")
         return atom_pred, pos_pred, prop_pred
 
+    def time_launch(self, label, graph, x, pos, t_index, reps=5):
+        """Mean duration in ms (HIP events on the launch stream) of one labelled launch of
+        the forward pass in situ; measurement hook used by bench.py."""
+        flags = _lib.FWD_T_BROADCAST | _lib.FWD_SKIP_PROP_HEAD
+        nbytes = self.lib.ligdiff_forward_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, flags)
+        ws = self.workspace(nbytes)
+        a = torch.empty(graph.n_atoms, 119, dtype=torch.float32, device=self.device)
+        p = torch.empty(graph.n_atoms, 3, dtype=torch.float32, device=self.device)
+        ms = C.c_float(0.0)
+        with torch.cuda.device(self.device):
+            rc = self.lib.ligdiff_forward_timed(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), None, _ptr(t_index),
+                                                None, flags, _ptr(a), _ptr(p), None, _ptr(ws), ws.numel(), _stream(),
+                                                label.encode(), int(reps), C.byref(ms))
+        check(rc, f"ligdiff_forward_timed({label})")
+        return float(ms.value)
+
     # ------------------------------------------------------------------ sampler entry points
     def step_args(self, model, x, pos, eps_x, eps_pos, eps_xu=None, eps_pu=None, guidance_scale=1.0,
                   temperature=1.0, t_index=None, noise_x=None, noise_pos=None, seed=0, atom_offset=0):

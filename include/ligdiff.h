@@ -123,6 +123,16 @@ int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, con
                     const float* properties, int flags, float* atom_pred, float* pos_pred,
                     float* prop_pred, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement hook (no counterpart in the reference): runs `reps` forwards and returns in
+ * *mean_ms_host (host pointer) the mean duration, from HIP events recorded on `stream`, of
+ * the one launch labelled `label` (e.g. "dit1.ffn_up", "e3_1.aggregate", "dit0.qkv").
+ * Creates two events and synchronises the stream; not for the serving path. */
+int ligdiff_forward_timed(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                          const float* pos, const float* t, const int32_t* t_index_dev,
+                          const float* properties, int flags, float* atom_pred, float* pos_pred,
+                          float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
+                          const char* label, int32_t reps, float* mean_ms_host);
+
 /* ---------------------------------------------------------------------------------
  * Fused reverse-diffusion updates.  Replace the per-step tensor arithmetic of
  * generation.py:457-484 (DDPM) and generation.py:359-381 (DDIM): schedule lookup,
