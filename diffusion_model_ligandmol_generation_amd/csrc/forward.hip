@@ -181,17 +181,33 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   PB("time.fourier");
   hipLaunchKernelGGL(k_fourier, dim3(Bt), dim3(128), 0, s, t, t_index_dev, w[W_TIME_FREQS], F(L.tf));
   PE();
-  PB("time.mlp0");
-  gemm_bias_act<ACT_GELU, false>(F(L.tf), 256, Bt, 256, w[W_T0_W], 256, w[W_T0_B], 2, F(L.t1), 512, nullptr, s);
-  PE();
-  PB("time.mlp2");
-  gemm_bias_act<ACT_NONE, true>(F(L.t1), 512, Bt, 512, w[W_T2_W], 512, w[W_T2_B], 1, F(L.temb), 256, F(L.stemb), s);
-  PE();
-  for (int l = 0; l < 3; ++l) {
-    PB("dit%d.adaln", l);
-    gemm_bias_act<ACT_NONE, false>(F(L.stemb), 256, Bt, 256, w[W_DIT(l, DIT_ADA_W)], 256, w[W_DIT(l, DIT_ADA_B)], 6,
-                                   F(L.mod[l]), 1536, nullptr, s);
+  if (Bt <= 4) {  // shared step index: a few rows -> wave-per-output linears
+    SmallLinearSets p0 = {{w[W_T0_W]}, {w[W_T0_B]}, {F(L.t1)}};
+    PB("time.mlp0");
+    hipLaunchKernelGGL((k_small_linear<1, false>), dim3(128, 1), dim3(256), 0, s, F(L.tf), p0, (float*)nullptr, Bt, 256, 512);
     PE();
+    SmallLinearSets p2 = {{w[W_T2_W]}, {w[W_T2_B]}, {F(L.temb)}};
+    PB("time.mlp2");
+    hipLaunchKernelGGL((k_small_linear<0, true>), dim3(64, 1), dim3(256), 0, s, F(L.t1), p2, F(L.stemb), Bt, 512, 256);
+    PE();
+    SmallLinearSets pa;
+    for (int l = 0; l < 3; ++l) { pa.W[l] = w[W_DIT(l, DIT_ADA_W)]; pa.b[l] = w[W_DIT(l, DIT_ADA_B)]; pa.C[l] = F(L.mod[l]); }
+    PB("dit.adaln");
+    hipLaunchKernelGGL((k_small_linear<0, false>), dim3(384, 3), dim3(256), 0, s, F(L.stemb), pa, (float*)nullptr, Bt, 256, 1536);
+    PE();
+  } else {
+    PB("time.mlp0");
+    gemm_bias_act<ACT_GELU, false>(F(L.tf), 256, Bt, 256, w[W_T0_W], 256, w[W_T0_B], 2, F(L.t1), 512, nullptr, s);
+    PE();
+    PB("time.mlp2");
+    gemm_bias_act<ACT_NONE, true>(F(L.t1), 512, Bt, 512, w[W_T2_W], 512, w[W_T2_B], 1, F(L.temb), 256, F(L.stemb), s);
+    PE();
+    for (int l = 0; l < 3; ++l) {
+      PB("dit%d.adaln", l);
+      gemm_bias_act<ACT_NONE, false>(F(L.stemb), 256, Bt, 256, w[W_DIT(l, DIT_ADA_W)], 256, w[W_DIT(l, DIT_ADA_B)], 6,
+                                     F(L.mod[l]), 1536, nullptr, s);
+      PE();
+    }
   }
 
   // --- PILOT conditioning (model1.py:714-718, :335-359)

@@ -151,17 +151,24 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmCore g, AL al, EP
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
       a[kk] = *reinterpret_cast<const f32x4*>(&sA[(wave * 32 + fi) * G_LDS + kk * 8 + hk * 4]);
+    // B fragments are read one column tile ahead of the MFMAs that consume them
+    f32x4 b[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      b[0][kk] = *reinterpret_cast<const f32x4*>(&sW[fi * G_LDS + kk * 8 + hk * 4]);
 #pragma unroll
     for (int ct = 0; ct < NT; ++ct) {
-      f32x4 b[4];
+      if (ct + 1 < NT) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-        b[kk] = *reinterpret_cast<const f32x4*>(&sW[(ct * 32 + fi) * G_LDS + kk * 8 + hk * 4]);
+        for (int kk = 0; kk < 4; ++kk)
+          b[(ct + 1) & 1][kk] =
+              *reinterpret_cast<const f32x4*>(&sW[((ct + 1) * 32 + fi) * G_LDS + kk * 8 + hk * 4]);
+      }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][j], b[kk][j], acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][j], b[ct & 1][kk][j], acc[ct], 0, 0, 0);
     }
     __syncthreads();
   }

@@ -16,6 +16,36 @@ __global__ void k_fourier(const float* __restrict__ t, const int32_t* __restrict
   out[(size_t)b * 256 + 128 + k] = cosf(e);
 }
 
+// Linear layer for a handful of rows (the time path when every molecule shares one step:
+// M = 1): one wave per output feature, k split over the lanes.  A 128-row MFMA tile would
+// run one workgroup for the whole layer; this spreads the weight read over the chip.
+//   C[m, o] = act(A[m,:] . W[o,:] + b[o]),  optional C2 = SiLU(C).  blockIdx.y picks a set.
+struct SmallLinearSets { const float* W[3]; const float* b[3]; float* C[3]; };
+template <int ACT, bool DUAL_SILU>
+__global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ A, SmallLinearSets p,
+                                                      float* __restrict__ C2, int M, int K, int Nout) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= Nout) return;
+  const float* W = p.W[blockIdx.y] + (size_t)o * K;
+  for (int m = 0; m < M; ++m) {
+    float s = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W + k);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)m * K + k);
+      s += (a[0] * w[0] + a[1] * w[1]) + (a[2] * w[2] + a[3] * w[3]);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      float v = s + p.b[blockIdx.y][o];
+      if (ACT == 1) v = gelu_exact(v);
+      if (ACT == 2) v = silu(v);
+      p.C[blockIdx.y][(size_t)m * Nout + o] = v;
+      if (DUAL_SILU) C2[(size_t)m * Nout + o] = silu(v);
+    }
+  }
+}
+
 // Edge geometry + radial MLP, model1.py:88-93, one lane per CSR edge:
 //   rel = pos[dst] - pos[src];  d = ||rel + 1e-8||;  rbf = W2 SiLU(w0 d + b0) + b2
 __global__ __launch_bounds__(256) void k_edge_geom(
