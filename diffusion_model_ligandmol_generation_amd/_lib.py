@@ -33,6 +33,15 @@ class StepArgs(C.Structure):
                 ("seed", C.c_uint64), ("atom_offset", C.c_int64), ("n_atoms", C.c_int64)]
 
 
+class LossArgs(C.Structure):
+    """struct ligdiff_loss_args"""
+    _fields_ = [("pos", C.c_void_p), ("noise", C.c_void_p), ("noisy", C.c_void_p), ("coef", C.c_void_p),
+                ("atom_pred", C.c_void_p), ("pos_pred", C.c_void_p), ("prop_pred", C.c_void_p),
+                ("properties", C.c_void_p), ("mol_ptr", C.c_void_p), ("n_mols", C.c_int32),
+                ("rot_mols", C.c_int32), ("n_atoms_global", C.c_int64), ("n_mols_global", C.c_int64),
+                ("workspace", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/ligdiff.h declares
 SIGNATURES = {
     "ligdiff_version": (C.c_int, []),
@@ -47,6 +56,17 @@ SIGNATURES = {
     "ligdiff_forward": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
+    "ligdiff_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    "ligdiff_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]),
+    "ligdiff_edm_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                      C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "ligdiff_loss_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "ligdiff_loss_partial": (C.c_int, [C.POINTER(LossArgs), C.c_void_p, C.c_void_p]),
+    "ligdiff_loss_finish": (C.c_int, [C.POINTER(LossArgs), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "ligdiff_forward_timed": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_float)]),

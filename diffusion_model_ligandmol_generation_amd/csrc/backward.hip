@@ -1,0 +1,317 @@
+// Score-network backward: reverse sweep over the activations kept by a forward run with
+// LIGDIFF_FWD_SAVE_FOR_BACKWARD.  Produces the gradient of every parameter the hot path
+// reads (the same set autograd reaches in the reference, train.py:195) into caller-owned,
+// pre-zeroed tensors.  Input gradients (x, pos, t, properties) are not produced: they are
+// data in the training step.
+#include <stdio.h>
+#include <string.h>
+
+#include "forward.h"
+#include "gemm_bwd.h"
+#include "kernels_bwd.h"
+#include "weights.h"
+
+struct BwdLayout {
+  size_t dxa, n256b, n256c, n256d, n512, n768, n1024, G;
+  size_t e256a, e256b, e256c, e128, e32a, e32b, e32c, e4;
+  size_t dmod[3], b256a, b256b, b256c, b256d, b512, b2048, b8, bhid;
+  size_t total;
+};
+static void bwd_layout(BwdLayout* L, int64_t N, int64_t E, int32_t B) {
+  size_t off = 0;
+  auto take = [&](size_t nfloats) { size_t o = off; off += align_up(nfloats * 4 + 16, 256); return o; };
+  L->dxa = take(N * 256); L->n256b = take(N * 256); L->n256c = take(N * 256); L->n256d = take(N * 256);
+  L->n512 = take(N * 512); L->n768 = take(N * 768); L->n1024 = take(N * 1024); L->G = take(N * 3);
+  L->e256a = take(E * 256); L->e256b = take(E * 256); L->e256c = take(E * 256); L->e128 = take(E * 128);
+  L->e32a = take(E * 32); L->e32b = take(E * 32); L->e32c = take(E * 32); L->e4 = take(E * 4);
+  for (int l = 0; l < 3; ++l) L->dmod[l] = take((size_t)B * 1536);
+  L->b256a = take((size_t)B * 256); L->b256b = take((size_t)B * 256); L->b256c = take((size_t)B * 256);
+  L->b256d = take((size_t)B * 256); L->b512 = take((size_t)B * 512); L->b2048 = take((size_t)B * 2048);
+  L->b8 = take((size_t)B * 8); L->bhid = take((size_t)B * 512);
+  L->total = off;
+}
+
+extern "C" size_t ligdiff_backward_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols) {
+  BwdLayout L;
+  bwd_layout(&L, n_atoms, n_edges, n_mols);
+  return L.total;
+}
+
+// C[M, ncols] (+)= dY[M, K] * W[K, ncols]  [* act'(pre)]     (W is the forward weight [out=K, in])
+template <int NT, int MUL, bool ACCUM>
+static void gemm_dx(const float* dY, int lddy, int M, int K, const float* W, int ldw, int ncols, float* C, int ldc,
+                    const float* pre, int ldp, hipStream_t s) {
+  if (M <= 0) return;
+  OpRow a{dY, lddy, M, K};
+  OpK b{W, ldw, ncols, K};
+  EpiBwdStore<NT, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f};
+  dim3 grid(ceil_div(M, G_BM), ceil_div(ncols, NT * 32), 1);
+  hipLaunchKernelGGL((gemm_bwd_kernel<NT, OpRow, OpK, EpiBwdStore<NT, MUL, ACCUM>>), grid, dim3(256), 0, s, a, b,
+                     (int)align_up(K, 32), e);
+}
+
+// dW[nout, kin] += dY[rows, nout]^T * X[rows, kin]   (split over rows, float atomics)
+template <int NT>
+static void gemm_dw(const float* dY, int lddy, int nout, const float* X, int ldx, int kin, int rows, float* dW,
+                    int lddw, hipStream_t s) {
+  if (rows <= 0) return;
+  OpK a{dY, lddy, nout, rows};
+  OpK b{X, ldx, kin, rows};
+  EpiBwdAtomic<NT> e{nout, kin, dW, lddw};
+  const int bx = ceil_div(nout, G_BM), by = ceil_div(kin, NT * 32);
+  int splits = ceil_div(1024, bx * by);
+  const int max_splits = ceil_div(rows, 128);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int k_split = (int)align_up(ceil_div(rows, splits), 32);
+  splits = ceil_div(rows, k_split);
+  dim3 grid(bx, by, splits);
+  hipLaunchKernelGGL((gemm_bwd_kernel<NT, OpK, OpK, EpiBwdAtomic<NT>>), grid, dim3(256), 0, s, a, b, k_split, e);
+}
+
+static void colsum(const float* Y, int ld, int M, int ncols, const float* rowscale, float* out, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL(k_colsum, dim3(ceil_div(M, 128), ceil_div(ncols, 256)), dim3(256), 0, s, Y, ld, M, ncols, rowscale, out);
+}
+
+template <int PRE, int POST>
+static void ln_bwd(const float* u, int ldu, const float* gamma, const float* beta, float eps, const float* dy, int ldy,
+                   const float* dy2, int ld2, const int32_t* idx, float* du, int ldo, float* dgamma, float* dbeta,
+                   int M, hipStream_t s) {
+  if (M <= 0) return;
+  hipLaunchKernelGGL((k_ln_bwd<PRE, POST>), dim3(ceil_div(M, 32)), dim3(256), 0, s, u, ldu, gamma, beta, eps, dy, ldy, dy2,
+                     ld2, idx, du, ldo, dgamma, dbeta, M);
+}
+
+__global__ void k_gelu_elem(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = gelu_exact(in[i]);
+}
+
+extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const ligdiff_graph* g, const float* x,
+                                const float* pos, const float* properties, int flags, const float* d_atom,
+                                const float* d_pos, const float* d_prop, const void* fwd_workspace,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!w || !gr || !g || !x || !pos || !d_atom || !d_pos || !fwd_workspace || !workspace) return LIGDIFF_ERR_ARG;
+  if (!(flags & LIGDIFF_FWD_SAVE_FOR_BACKWARD) || (flags & LIGDIFF_FWD_T_BROADCAST)) return LIGDIFF_ERR_ARG;
+  for (int i = 0; i < W_COUNT; ++i)
+    if (w[i] == nullptr || (i != W_TIME_FREQS && gr[i] == nullptr)) return LIGDIFF_ERR_ARG;
+  const int N = (int)g->n_atoms, E = (int)g->n_edges, B = g->n_mols;
+  FwdLayout F;
+  fwd_layout(&F, N, E, B, flags);
+  BwdLayout L;
+  bwd_layout(&L, N, E, B);
+  if (workspace_bytes < L.total) return LIGDIFF_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const char* fws = (const char*)fwd_workspace;
+  char* ws = (char*)workspace;
+  auto A = [&](size_t off) { return reinterpret_cast<const float*>(fws + off); };  // saved activation
+  auto T = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };         // backward scratch
+  const int nb4N = ceil_div(N, 4), nb4B = ceil_div(B, 4);
+  float* dxa = T(L.dxa);
+
+  // ------------------------------------------------------------------ heads (model1.py:741-746)
+  const float* x_last = A(F.x2[2]);
+  float* dyh = T(L.n512);
+  gemm_dx<8, MUL_NONE, false>(d_atom, LD_A, N, LD_A, w[W_HEAD(0, HEAD_W3)], 256, 256, dyh, 512, nullptr, 0, s);
+  hipLaunchKernelGGL(k_small_dx<3>, dim3(nb4N), dim3(256), 0, s, d_pos, w[W_HEAD(1, HEAD_W3)], dyh, 512, 256, N);
+  gemm_dw<8>(d_atom, LD_A, LD_A, A(F.yh), 512, 256, N, gr[W_HEAD(0, HEAD_W3)], 256, s);
+  colsum(d_atom, LD_A, N, LD_A, nullptr, gr[W_HEAD(0, HEAD_B3)], s);
+  hipLaunchKernelGGL(k_small_dw<3>, dim3(ceil_div(N, 128)), dim3(256), 0, s, d_pos, A(F.yh), 512, 256,
+                     gr[W_HEAD(1, HEAD_W3)], gr[W_HEAD(1, HEAD_B3)], N);
+  for (int h = 0; h < 2; ++h) {
+    ln_bwd<1, 0>(A(F.u_head) + h * 256, 512, w[W_HEAD(h, HEAD_G)], w[W_HEAD(h, HEAD_BE)], 1e-5f, dyh + h * 256, 512,
+                 nullptr, 0, nullptr, dyh + h * 256, 512, gr[W_HEAD(h, HEAD_G)], gr[W_HEAD(h, HEAD_BE)], N, s);
+    gemm_dw<8>(dyh + h * 256, 512, 256, x_last, 256, 256, N, gr[W_HEAD(h, HEAD_W0)], 256, s);
+    colsum(dyh + h * 256, 512, N, 256, nullptr, gr[W_HEAD(h, HEAD_B0)], s);
+  }
+  gemm_dx<8, MUL_NONE, false>(dyh, 512, N, 256, w[W_HEAD(0, HEAD_W0)], 256, 256, dxa, 256, nullptr, 0, s);
+  gemm_dx<8, MUL_NONE, true>(dyh + 256, 512, N, 256, w[W_HEAD(1, HEAD_W0)], 256, 256, dxa, 256, nullptr, 0, s);
+  if (d_prop != nullptr && !(flags & LIGDIFF_FWD_SKIP_PROP_HEAD)) {
+    float* dph = T(L.b256a);
+    hipLaunchKernelGGL(k_small_dx<15>, dim3(nb4B), dim3(256), 0, s, d_prop, w[W_HEAD(2, HEAD_W3)], dph, 256, 0, B);
+    hipLaunchKernelGGL(k_small_dw<15>, dim3(ceil_div(B, 128)), dim3(256), 0, s, d_prop, A(F.ph), 256, 0,
+                       gr[W_HEAD(2, HEAD_W3)], gr[W_HEAD(2, HEAD_B3)], B);
+    ln_bwd<1, 0>(A(F.u_ph), 256, w[W_HEAD(2, HEAD_G)], w[W_HEAD(2, HEAD_BE)], 1e-5f, dph, 256, nullptr, 0, nullptr, dph,
+                 256, gr[W_HEAD(2, HEAD_G)], gr[W_HEAD(2, HEAD_BE)], B, s);
+    gemm_dw<8>(dph, 256, 256, A(F.pooled), 256, 256, B, gr[W_HEAD(2, HEAD_W0)], 256, s);
+    colsum(dph, 256, B, 256, nullptr, gr[W_HEAD(2, HEAD_B0)], s);
+    float* dpool = T(L.b256b);
+    gemm_dx<8, MUL_NONE, false>(dph, 256, B, 256, w[W_HEAD(2, HEAD_W0)], 256, 256, dpool, 256, nullptr, 0, s);
+    hipLaunchKernelGGL(k_pool_bwd, dim3(nb4N), dim3(256), 0, s, dpool, g->mol_ptr, g->atom_mol, dxa, N);
+  }
+  float* G = T(L.G);  // gradient w.r.t. the accumulated coordinate update (model1.py:742)
+  if (hipMemcpyAsync(G, d_pos, (size_t)N * 3 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return LIGDIFF_ERR_LAUNCH;
+
+  // ------------------------------------------------------------------ DiT layers (model1.py:279-302)
+  const size_t att_lds_hpb4 = (size_t)4 * (g->max_mol_atoms <= 64 ? 64 : 128) * 130 * 4;
+  for (int l = 2; l >= 0; --l) {
+    const float* x_in = (l == 0) ? A(F.h_e3[2]) : A(F.x2[l - 1]);
+    const float* mod = A(F.mod[l]);
+    float* dmod = T(L.dmod[l]);
+    float* t256b = T(L.n256b);
+    float* t256c = T(L.n256c);
+    // x2 = x1 + gate_mlp * (ffh W3^T + b)
+    hipLaunchKernelGGL(k_gate_bwd, dim3(nb4B), dim3(256), 0, s, dxa, A(F.fproj[l]), mod, 1536, 1280, g->mol_ptr, B, t256b, dmod);
+    gemm_dw<8>(t256b, 256, 256, A(F.ffh[l]), 1024, 1024, N, gr[W_DIT(l, DIT_FF3_W)], 1024, s);
+    colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_FF3_B)], s);
+    float* dffh = T(L.n1024);
+    gemm_dx<8, MUL_GELU_GRAD, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1024, dffh, 1024,
+                                     A(F.ffh_pre[l]), 1024, s);
+    gemm_dw<8>(dffh, 1024, 1024, A(F.xn2[l]), 256, 256, N, gr[W_DIT(l, DIT_FF0_W)], 256, s);
+    colsum(dffh, 1024, N, 1024, nullptr, gr[W_DIT(l, DIT_FF0_B)], s);
+    gemm_dx<8, MUL_NONE, false>(dffh, 1024, N, 1024, w[W_DIT(l, DIT_FF0_W)], 256, 256, t256c, 256, nullptr, 0, s);
+    hipLaunchKernelGGL(k_lnmod_bwd, dim3(nb4B), dim3(256), 0, s, A(F.x1[l]), t256c, dxa, mod, 1536, 768, 1024,
+                       g->mol_ptr, B, dxa, dmod);
+    // x1 = x_in + gate_msa * (att Wo^T + b)
+    hipLaunchKernelGGL(k_gate_bwd, dim3(nb4B), dim3(256), 0, s, dxa, A(F.oproj[l]), mod, 1536, 512, g->mol_ptr, B, t256b, dmod);
+    gemm_dw<8>(t256b, 256, 256, A(F.att[l]), 256, 256, N, gr[W_DIT(l, DIT_OUT_W)], 256, s);
+    colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_OUT_B)], s);
+    gemm_dx<8, MUL_NONE, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_OUT_W)], 256, 256, t256c, 256, nullptr, 0, s);
+    float* dqkv = T(L.n768);
+    if (g->max_mol_atoms <= 64) {
+      hipLaunchKernelGGL(k_attention_bwd, dim3(B * 2), dim3(256), att_lds_hpb4, s, A(F.qkv[l]), A(F.att[l]), t256c,
+                         A(F.lse[l]), g->mol_ptr, dqkv, 64);
+    } else {
+      hipLaunchKernelGGL(k_attention_bwd, dim3(B * 4), dim3(128), att_lds_hpb4 / 2, s, A(F.qkv[l]), A(F.att[l]), t256c,
+                         A(F.lse[l]), g->mol_ptr, dqkv, 128);
+    }
+    gemm_dw<8>(dqkv, 768, 768, A(F.xn1[l]), 256, 256, N, gr[W_DIT(l, DIT_INP_W)], 256, s);
+    colsum(dqkv, 768, N, 768, nullptr, gr[W_DIT(l, DIT_INP_B)], s);
+    gemm_dx<8, MUL_NONE, false>(dqkv, 768, N, 768, w[W_DIT(l, DIT_INP_W)], 256, 256, t256c, 256, nullptr, 0, s);
+    hipLaunchKernelGGL(k_lnmod_bwd, dim3(nb4B), dim3(256), 0, s, x_in, t256c, dxa, mod, 1536, 0, 256, g->mol_ptr, B,
+                       dxa, dmod);
+  }
+
+  // ------------------------------------------------------------------ E(3) layers (model1.py:86-114, :721-725)
+  for (int l = 2; l >= 0; --l) {
+    const float* h_in = (l == 0) ? A(F.h0) : A(F.h_e3[l - 1]);
+    const float* W1 = w[W_E3(l, E3_EN0_W)];
+    float* dW1 = gr[W_E3(l, E3_EN0_W)];
+    float* t256b = T(L.n256b);
+    float* t256c = T(L.n256c);
+    float* dagg = T(L.n256d);
+    // h_out = h_in + LN(hid Wn2^T + b)
+    ln_bwd<0, 0>(A(F.u_h[l]), 256, w[W_E3(l, E3_NN3_G)], w[W_E3(l, E3_NN3_B)], 1e-5f, dxa, 256, nullptr, 0, nullptr,
+                 t256b, 256, gr[W_E3(l, E3_NN3_G)], gr[W_E3(l, E3_NN3_B)], N, s);
+    gemm_dw<8>(t256b, 256, 256, A(F.hid[l]), 256, 256, N, gr[W_E3(l, E3_NN2_W)], 256, s);
+    colsum(t256b, 256, N, 256, nullptr, gr[W_E3(l, E3_NN2_B)], s);
+    gemm_dx<8, MUL_SILU_GRAD, false>(t256b, 256, N, 256, w[W_E3(l, E3_NN2_W)], 256, 256, t256c, 256, A(F.hid_pre[l]),
+                                     256, s);
+    gemm_dw<8>(t256c, 256, 256, h_in, 256, 256, N, gr[W_E3(l, E3_NN0_W)], 512, s);
+    gemm_dw<8>(t256c, 256, 256, A(F.agg[l]), 256, 256, N, gr[W_E3(l, E3_NN0_W)] + 256, 512, s);
+    colsum(t256c, 256, N, 256, nullptr, gr[W_E3(l, E3_NN0_B)], s);
+    gemm_dx<8, MUL_NONE, true>(t256c, 256, N, 256, w[W_E3(l, E3_NN0_W)], 512, 256, dxa, 256, nullptr, 0, s);
+    gemm_dx<8, MUL_NONE, false>(t256c, 256, N, 256, w[W_E3(l, E3_NN0_W)] + 256, 512, 256, dagg, 256, nullptr, 0, s);
+    if (E > 0) {
+      float* drel = T(L.e4);
+      float* dhc = T(L.e128);
+      float* e256a = T(L.e256a);
+      float* e256b = T(L.e256b);
+      float* dpre = T(L.e256c);
+      // coordinate gate
+      hipLaunchKernelGGL(k_coord_bwd, dim3(1024), dim3(256), 0, s, G, g->src, g->dst, A(F.rel[l]), A(F.cw[l]),
+                         A(F.hc_pre[l]), w[W_E3(l, E3_CN2_W)], drel, dhc, gr[W_E3(l, E3_CN2_W)], gr[W_E3(l, E3_CN2_B)], E);
+      gemm_dw<8>(dhc, 128, 128, A(F.msg[l]), 256, 256, E, gr[W_E3(l, E3_CN0_W)], 256, s);
+      colsum(dhc, 128, E, 128, nullptr, gr[W_E3(l, E3_CN0_B)], s);
+      gemm_dx<8, MUL_NONE, false>(dhc, 128, E, 128, w[W_E3(l, E3_CN0_W)], 256, 256, e256a, 256, nullptr, 0, s);
+      // msg = LN(a1 W2^T + b); its gradient = coordinate branch + aggregated branch (dagg[dst])
+      ln_bwd<0, 0>(A(F.u_m[l]), 256, w[W_E3(l, E3_EN3_G)], w[W_E3(l, E3_EN3_B)], 1e-5f, e256a, 256, dagg, 256, g->dst,
+                   e256b, 256, gr[W_E3(l, E3_EN3_G)], gr[W_E3(l, E3_EN3_B)], E, s);
+      gemm_dw<8>(e256b, 256, 256, A(F.a1[l]), 256, 256, E, gr[W_E3(l, E3_EN2_W)], 256, s);
+      colsum(e256b, 256, E, 256, nullptr, gr[W_E3(l, E3_EN2_B)], s);
+      gemm_dx<8, MUL_SILU_GRAD, false>(e256b, 256, E, 256, w[W_E3(l, E3_EN2_W)], 256, 256, dpre, 256, A(F.pre_e[l]),
+                                       256, s);
+      // pre = Pa[src] + Pb[dst] + Wc rbf + b1
+      colsum(dpre, 256, E, 256, nullptr, gr[W_E3(l, E3_EN0_B)], s);
+      gemm_dw<4>(dpre, 256, 256, A(F.rbf[l]), 32, 32, E, dW1 + 512, 544, s);
+      float* drbf = T(L.e32a);
+      gemm_dx<4, MUL_NONE, false>(dpre, 256, E, 256, W1 + 512, 544, 32, drbf, 32, nullptr, 0, s);
+      float* dr1pre = T(L.e32b);
+      float* r1 = T(L.e32c);
+      hipLaunchKernelGGL(k_radial_bwd, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, A(F.r1pre[l]), A(F.dist[l]),
+                         A(F.rel[l]), w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB2_W)], drel, dr1pre, r1, E);
+      gemm_dw<4>(drbf, 32, 32, r1, 32, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s);
+      colsum(drbf, 32, E, 32, nullptr, gr[W_E3(l, E3_RB2_B)], s);
+      colsum(dr1pre, 32, E, 32, A(F.dist[l]), gr[W_E3(l, E3_RB0_W)], s);
+      colsum(dr1pre, 32, E, 32, nullptr, gr[W_E3(l, E3_RB0_B)], s);
+      float* dP = T(L.n512);
+      hipLaunchKernelGGL(k_dp_gather, dim3(nb4N), dim3(256), 0, s, dpre, g->dst_ptr, g->src_ptr, g->src_slot, dP, N);
+      gemm_dw<8>(dP, 512, 256, h_in, 256, 256, N, dW1, 544, s);
+      gemm_dw<8>(dP + 256, 512, 256, h_in, 256, 256, N, dW1 + 256, 544, s);
+      gemm_dx<8, MUL_NONE, true>(dP, 512, N, 256, W1, 544, 256, dxa, 256, nullptr, 0, s);
+      gemm_dx<8, MUL_NONE, true>(dP + 256, 512, N, 256, W1 + 256, 544, 256, dxa, 256, nullptr, 0, s);
+      if (l > 0)  // layer 0 reads the data coordinates: no parameter lies upstream of them
+        hipLaunchKernelGGL(k_pos_scatter_bwd, dim3(nb4N), dim3(256), 0, s, drel, g->dst_ptr, g->src_ptr, g->src_slot, G, N);
+    }
+  }
+
+  // ------------------------------------------------------------------ embeddings (model1.py:709-718)
+  {
+    float* du = T(L.n256b);
+    ln_bwd<0, 1>(A(F.ua), 256, w[W_ATOM_G], w[W_ATOM_BE], 1e-5f, dxa, 256, nullptr, 0, nullptr, du, 256, gr[W_ATOM_G],
+                 gr[W_ATOM_BE], N, s);
+    gemm_dw<4>(du, 256, 256, x, LD_A, LD_A, N, gr[W_ATOM_W], LD_A, s);
+    colsum(du, 256, N, 256, nullptr, gr[W_ATOM_B], s);
+    float* up = T(L.n256c);
+    float* dup = T(L.n256d);
+    hipLaunchKernelGGL(k_pos_embed_pre, dim3(nb4N), dim3(256), 0, s, pos, w[W_POS_W], w[W_POS_B], up, N);
+    ln_bwd<0, 1>(up, 256, w[W_POS_G], w[W_POS_BE], 1e-5f, dxa, 256, nullptr, 0, nullptr, dup, 256, gr[W_POS_G],
+                 gr[W_POS_BE], N, s);
+    hipLaunchKernelGGL(k_pos_embed_dw, dim3(ceil_div(N, 128)), dim3(256), 0, s, dup, pos, gr[W_POS_W], N);
+    colsum(dup, 256, N, 256, nullptr, gr[W_POS_B], s);
+  }
+  float* dmolsum = T(L.b256a);  // sum over each molecule's atoms of dh0: gradient of t_emb[mol] and prop_emb[mol]
+  hipLaunchKernelGGL(k_mol_sum, dim3(nb4B), dim3(256), 0, s, dxa, g->mol_ptr, B, dmolsum);
+
+  // ------------------------------------------------------------------ PILOT conditioning (model1.py:335-359)
+  if (flags & LIGDIFF_FWD_PROPERTIES) {
+    if (flags & LIGDIFF_FWD_NULL_COND) {
+      colsum(dmolsum, 256, B, 256, nullptr, gr[W_NULL_EMB], s);
+    } else {
+      if (properties == nullptr) return LIGDIFF_ERR_ARG;
+      float* dstk = T(L.b2048);
+      float* dz = T(L.b8);
+      float* dgpre = T(L.b256d);
+      float* hid = T(L.bhid);
+      hipLaunchKernelGGL(k_pilot_combine_bwd, dim3(B), dim3(256), 0, s, dmolsum, A(F.pstack), A(F.pz), A(F.pw), dstk, dz);
+      hipLaunchKernelGGL(k_pilot_dw2, dim3(ceil_div(B, 64)), dim3(256), 0, s, dz, A(F.pg), B, gr[W_PAR2_W], gr[W_PAR2_B]);
+      hipLaunchKernelGGL(k_pilot_dg, dim3(B), dim3(256), 0, s, dz, w[W_PAR2_W], A(F.pg_pre), dgpre);
+      gemm_dw<8>(dgpre, 256, 256, A(F.pstack), 2048, 2048, B, gr[W_PAR0_W], 2048, s);
+      colsum(dgpre, 256, B, 256, nullptr, gr[W_PAR0_B], s);
+      gemm_dx<8, MUL_NONE, true>(dgpre, 256, B, 256, w[W_PAR0_W], 2048, 2048, dstk, 2048, nullptr, 0, s);
+      hipLaunchKernelGGL(k_gelu_elem, dim3(ceil_div((int64_t)B * 512, 256)), dim3(256), 0, s, A(F.pen_pre), hid, (int64_t)B * 512);
+      PilotEncGrads pg;
+      for (int e = 0; e < 8; ++e) {
+        gemm_dw<4>(dstk + e * 256, 2048, 256, hid + e * 64, 512, 64, B, gr[W_PENC(e, 2)], 64, s);
+        colsum(dstk + e * 256, 2048, B, 256, nullptr, gr[W_PENC(e, 3)], s);
+        pg.W2[e] = w[W_PENC(e, 2)]; pg.dw0[e] = gr[W_PENC(e, 0)]; pg.db0[e] = gr[W_PENC(e, 1)];
+      }
+      hipLaunchKernelGGL(k_pilot_enc_bwd, dim3(B, 8), dim3(64), 0, s, dstk, A(F.pen_pre), properties, pg);
+    }
+  }
+
+  // ------------------------------------------------------------------ time path (model1.py:705-706, :288)
+  {
+    float* dstemb = T(L.b256b);
+    for (int l = 0; l < 3; ++l) {
+      const float* dmod = T(L.dmod[l]);
+      if (l == 0)
+        gemm_dx<8, MUL_NONE, false>(dmod, 1536, B, 1536, w[W_DIT(l, DIT_ADA_W)], 256, 256, dstemb, 256, nullptr, 0, s);
+      else
+        gemm_dx<8, MUL_NONE, true>(dmod, 1536, B, 1536, w[W_DIT(l, DIT_ADA_W)], 256, 256, dstemb, 256, nullptr, 0, s);
+      gemm_dw<8>(dmod, 1536, 1536, A(F.stemb), 256, 256, B, gr[W_DIT(l, DIT_ADA_W)], 256, s);
+      colsum(dmod, 1536, B, 1536, nullptr, gr[W_DIT(l, DIT_ADA_B)], s);
+    }
+    float* dtemb = T(L.b256c);
+    hipLaunchKernelGGL(k_time_bwd_elem, dim3(ceil_div(B * 256, 256)), dim3(256), 0, s, dmolsum, dstemb, A(F.temb), dtemb, B * 256);
+    gemm_dw<8>(dtemb, 256, 256, A(F.t1), 512, 512, B, gr[W_T2_W], 512, s);
+    colsum(dtemb, 256, B, 256, nullptr, gr[W_T2_B], s);
+    float* dt1 = T(L.b512);
+    gemm_dx<8, MUL_GELU_GRAD, false>(dtemb, 256, B, 256, w[W_T2_W], 512, 512, dt1, 512, A(F.t1_pre), 512, s);
+    gemm_dw<8>(dt1, 512, 512, A(F.tf), 256, 256, B, gr[W_T0_W], 256, s);
+    colsum(dt1, 512, B, 512, nullptr, gr[W_T0_B], s);
+  }
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}

@@ -15,6 +15,7 @@ struct EpiEmbed {
   const float* pemb; int pemb_stride;   // nullable
   const int32_t* atom_mol;
   float* H;
+  float* ua_out;  // nullable: x Wa^T + ba (pre-LayerNorm), kept for backward
   __device__ __forceinline__ void operator()(f32x16 (&acc)[8], int row0, int by, int lane) const {
     const int c0 = lane & 31;
 #pragma unroll 1
@@ -51,6 +52,7 @@ struct EpiEmbed {
           float h = (y1 + y2) + temb[(size_t)mol * temb_stride + col];
           if (pemb != nullptr) h += pemb[(size_t)mol * pemb_stride + col];
           H[(size_t)row * 256 + col] = h;
+          if (ua_out != nullptr) ua_out[(size_t)row * 256 + col] = v[ct];
         }
       }
     }
@@ -70,6 +72,7 @@ struct EpiGate {
   const int32_t* atom_mol;
   float* X;                                 // [M,256]
   float* XN;                                // [M,256] (LNMOD)
+  float* proj_out;                          // nullable: acc + bias (kept for backward)
   __device__ __forceinline__ void operator()(f32x16 (&acc)[8], int row0, int by, int lane) const {
     const int c0 = lane & 31;
     float bv[8];
@@ -85,8 +88,10 @@ struct EpiGate {
 #pragma unroll
       for (int ct = 0; ct < 8; ++ct) {
         const int col = ct * 32 + c0;
-        v[ct] = resid[(size_t)rr * 256 + col] + g[col] * (acc[ct][r] + bv[ct]);
+        const float pr = acc[ct][r] + bv[ct];
+        v[ct] = resid[(size_t)rr * 256 + col] + g[col] * pr;
         s += v[ct];
+        if (proj_out != nullptr && row < M) proj_out[(size_t)row * 256 + col] = pr;
       }
       float mean = 0.f, rstd = 0.f;
       if (LNMOD) {
@@ -115,14 +120,13 @@ struct EpiGate {
 //   W1 [h_src | h_dst | rbf] + b1 = Pa[src] + Pb[dst] + Wc rbf + b1
 // with Pa|Pb = h [W1a|W1b]^T computed once per NODE (P is [N,512]); the accumulators hold
 // Wc rbf (K = 32).  Stores SiLU(.) as the A operand of the second edge linear.
-template <bool SAVE>
 struct EpiEdgePre {
   int M;  // edges
   const float* b1;
   const float* P;  // [N,512]
   const int32_t* src; const int32_t* dst;
   float* A1;       // [E,256]
-  float* pre_out;  // SAVE: pre-activation
+  float* pre_out;  // nullable: pre-activation
   __device__ __forceinline__ void operator()(f32x16 (&acc)[8], int row0, int by, int lane) const {
     const int c0 = lane & 31;
     float bv[8];
@@ -139,7 +143,7 @@ struct EpiEdgePre {
           const int col = ct * 32 + c0;
           const float v = (pa[col] + pb[col]) + (acc[ct][r] + bv[ct]);
           A1[(size_t)row * 256 + col] = silu(v);
-          if (SAVE) pre_out[(size_t)row * 256 + col] = v;
+          if (pre_out != nullptr) pre_out[(size_t)row * 256 + col] = v;
         }
       }
     }
@@ -148,7 +152,6 @@ struct EpiEdgePre {
 
 // Coordinate gate, model1.py:79-84 / :106-107 (NT = 4, 128 hidden units):
 //   cw = tanh(w2 . SiLU(acc + b1) + b2);  wrel = rel * cw
-template <bool SAVE>
 struct EpiCoord {
   int M;
   const float* b1;   // [128]
@@ -156,8 +159,8 @@ struct EpiCoord {
   const float* b2;   // [1]
   const float* rel;  // [E,4] (xyz + pad)
   float* wrel;       // [E,4]
-  float* hid_out;    // SAVE: [E,128] pre-activation
-  float* cw_out;     // SAVE: [E]
+  float* hid_out;    // nullable: [E,128] pre-activation
+  float* cw_out;     // nullable: [E]
   __device__ __forceinline__ void operator()(f32x16 (&acc)[4], int row0, int by, int lane) const {
     const int c0 = lane & 31;
     float bv[4], wv[4];
@@ -172,11 +175,11 @@ struct EpiCoord {
       for (int ct = 0; ct < 4; ++ct) {
         const float u = acc[ct][r] + bv[ct];
         s += silu(u) * wv[ct];
-        if (SAVE && row < M) hid_out[(size_t)row * 128 + ct * 32 + c0] = u;
+        if (hid_out != nullptr && row < M) hid_out[(size_t)row * 128 + ct * 32 + c0] = u;
       }
       const float cw = tanhf(half_wave_sum(s) + bias2);
       if (row < M && c0 < 3) wrel[(size_t)row * 4 + c0] = rel[(size_t)row * 4 + c0] * cw;
-      if (SAVE && row < M && c0 == 3) cw_out[row] = cw;
+      if (cw_out != nullptr && row < M && c0 == 3) cw_out[row] = cw;
     }
   }
 };

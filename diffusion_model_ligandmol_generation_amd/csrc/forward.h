@@ -17,6 +17,11 @@ struct FwdLayout {
   size_t xn1[3], qkv[3], att[3], x1[3], xn2[3], ffh[3], x2[3];
   size_t yh;                        // [N,512] head hidden (atom | pos)
   size_t pooled, ph;                // [B,256]
+  // kept only with LIGDIFF_FWD_SAVE_FOR_BACKWARD (pre-activations the backward pass needs)
+  int save;
+  size_t t1_pre, ua, pen_pre, pg_pre, pz, pw;
+  size_t pre_e[3], u_m[3], hc_pre[3], cw[3], dist[3], r1pre[3], hid_pre[3], u_h[3];
+  size_t oproj[3], fproj[3], ffh_pre[3], lse[3], u_head, u_ph;
   size_t total;
 };
 void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags);

@@ -110,12 +110,13 @@ static GemmCore core_blocks(int M, int K, int n_valid, const float* W, int ldw, 
 // y[M, nb*256] = act(A[M,K] W^T + b)
 template <int ACT, bool DUAL>
 static void gemm_bias_act(const float* A, int lda, int M, int K, const float* W, int ldw, const float* bias,
-                          int nb, float* C, int ldc, float* C2, hipStream_t s) {
+                          int nb, float* C, int ldc, float* C2, hipStream_t s, float* pre_out = nullptr) {
   GemmCore g = core_blocks(M, K, 256, W, ldw, nb, 256);
   ALoadPlain al{A, lda, M, K};
   EpiBiasAct<8, ACT, DUAL> e;
   memset(&e, 0, sizeof e);
   e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = ldc; e.C2 = C2; e.alpha = 1.0f;
+  e.pre_out = pre_out;
   for (int i = 0; i < nb; ++i) e.bias[i] = bias ? bias + (size_t)i * 256 : nullptr;
   launch_gemm<8, W_ALIGNED>(g, al, e, nb, s);
 }
@@ -150,6 +151,20 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
   stream_buf(L->h_e3); stream_buf(L->x1); stream_buf(L->x2);
   L->yh = take(N * 512);
   L->pooled = take((size_t)B * 256); L->ph = take((size_t)B * 256);
+  L->save = save ? 1 : 0;
+  if (save) {
+    L->t1_pre = take(Bt * 512); L->ua = take(N * 256);
+    L->pen_pre = take((size_t)B * 512); L->pg_pre = take((size_t)B * 256);
+    L->pz = take((size_t)B * 8); L->pw = take((size_t)B * 8);
+    for (int l = 0; l < 3; ++l) {
+      L->pre_e[l] = take(E * 256); L->u_m[l] = take(E * 256); L->hc_pre[l] = take(E * 128);
+      L->cw[l] = take(E); L->dist[l] = take(E); L->r1pre[l] = take(E * 32);
+      L->hid_pre[l] = take(N * 256); L->u_h[l] = take(N * 256);
+      L->oproj[l] = take(N * 256); L->fproj[l] = take(N * 256); L->ffh_pre[l] = take(N * 1024);
+      L->lse[l] = take(N * 8);
+    }
+    L->u_head = take(N * 512); L->u_ph = take((size_t)B * 256);
+  }
   L->total = off;
 }
 
@@ -173,6 +188,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   FwdLayout L;
   fwd_layout(&L, N, E, B, flags);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+  auto S = [&](size_t off) { return L.save ? reinterpret_cast<float*>(ws + off) : (float*)nullptr; };
   const int Bt = (int)L.Bt;
   const int tstride = (flags & LIGDIFF_FWD_T_BROADCAST) ? 0 : 256;
   const int mstride = (flags & LIGDIFF_FWD_T_BROADCAST) ? 0 : 1536;
@@ -181,7 +197,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   PB("time.fourier");
   hipLaunchKernelGGL(k_fourier, dim3(Bt), dim3(128), 0, s, t, t_index_dev, w[W_TIME_FREQS], F(L.tf));
   PE();
-  if (Bt <= 4) {  // shared step index: a few rows -> wave-per-output linears
+  if (Bt <= 4 && !L.save) {  // shared step index: a few rows -> wave-per-output linears
     SmallLinearSets p0 = {{w[W_T0_W]}, {w[W_T0_B]}, {F(L.t1)}};
     PB("time.mlp0");
     hipLaunchKernelGGL((k_small_linear<1, false>), dim3(128, 1), dim3(256), 0, s, F(L.tf), p0, (float*)nullptr, Bt, 256, 512);
@@ -197,7 +213,8 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     PE();
   } else {
     PB("time.mlp0");
-    gemm_bias_act<ACT_GELU, false>(F(L.tf), 256, Bt, 256, w[W_T0_W], 256, w[W_T0_B], 2, F(L.t1), 512, nullptr, s);
+    gemm_bias_act<ACT_GELU, false>(F(L.tf), 256, Bt, 256, w[W_T0_W], 256, w[W_T0_B], 2, F(L.t1), 512, nullptr, s,
+                                   S(L.t1_pre));
     PE();
     PB("time.mlp2");
     gemm_bias_act<ACT_NONE, true>(F(L.t1), 512, Bt, 512, w[W_T2_W], 512, w[W_T2_B], 1, F(L.temb), 256, F(L.stemb), s);
@@ -223,9 +240,11 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         pw.w0[i] = w[W_PENC(i, 0)]; pw.b0[i] = w[W_PENC(i, 1)];
         pw.W2[i] = w[W_PENC(i, 2)]; pw.b2[i] = w[W_PENC(i, 3)];
       }
-      hipLaunchKernelGGL(k_pilot_encode, dim3(B), dim3(256), 0, s, properties, pw, F(L.pstack));
-      gemm_bias_act<ACT_GELU, false>(F(L.pstack), 2048, B, 2048, w[W_PAR0_W], 2048, w[W_PAR0_B], 1, F(L.pg), 256, nullptr, s);
-      hipLaunchKernelGGL(k_pilot_combine, dim3(B), dim3(256), 0, s, F(L.pg), w[W_PAR2_W], w[W_PAR2_B], F(L.pstack), F(L.pemb));
+      hipLaunchKernelGGL(k_pilot_encode, dim3(B), dim3(256), 0, s, properties, pw, F(L.pstack), S(L.pen_pre));
+      gemm_bias_act<ACT_GELU, false>(F(L.pstack), 2048, B, 2048, w[W_PAR0_W], 2048, w[W_PAR0_B], 1, F(L.pg), 256, nullptr, s,
+                                     S(L.pg_pre));
+      hipLaunchKernelGGL(k_pilot_combine, dim3(B), dim3(256), 0, s, F(L.pg), w[W_PAR2_W], w[W_PAR2_B], F(L.pstack), F(L.pemb),
+                         S(L.pz), S(L.pw));
       pemb = F(L.pemb); pstride = 256;
     }
   }
@@ -238,7 +257,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     e.M = N; e.ba = w[W_ATOM_B]; e.ga = w[W_ATOM_G]; e.bea = w[W_ATOM_BE];
     e.pos = pos; e.Wp = w[W_POS_W]; e.bp = w[W_POS_B]; e.gp = w[W_POS_G]; e.bep = w[W_POS_BE];
     e.temb = F(L.temb); e.temb_stride = tstride; e.pemb = pemb; e.pemb_stride = pstride;
-    e.atom_mol = g->atom_mol; e.H = F(L.h0);
+    e.atom_mol = g->atom_mol; e.H = F(L.h0); e.ua_out = S(L.ua);
     PB("embed");
     launch_gemm<8, W_SCALAR>(gc, al, e, 1, s);
     PE();
@@ -266,14 +285,14 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       PB("e3_%d.edge_geom", l);
       hipLaunchKernelGGL(k_edge_geom, dim3(ceil_div(E, 256)), dim3(256), 0, s, pos_l, g->src, g->dst,
                          w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB0_B)], w[W_E3(l, E3_RB2_W)], w[W_E3(l, E3_RB2_B)],
-                         F(L.rel[l]), F(L.rbf[l]), (float*)nullptr, E);
+                         F(L.rel[l]), F(L.rbf[l]), S(L.dist[l]), S(L.r1pre[l]), E);
       PE();
       {  // a1 = SiLU(Pa[src] + Pb[dst] + Wc rbf + b1)
         GemmCore gc;
         memset(&gc, 0, sizeof gc);
         gc.M = E; gc.K = 32; gc.n_valid = 256; gc.ldw = 544; gc.W[0] = w[W_E3(l, E3_EN0_W)] + 512;
         ALoadPlain al{F(L.rbf[l]), 32, E, 32};
-        EpiEdgePre<false> e{E, w[W_E3(l, E3_EN0_B)], F(L.P[l]), g->src, g->dst, F(L.a1[l]), nullptr};
+        EpiEdgePre e{E, w[W_E3(l, E3_EN0_B)], F(L.P[l]), g->src, g->dst, F(L.a1[l]), S(L.pre_e[l])};
         PB("e3_%d.edge_pre", l);
         launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
         PE();
@@ -281,10 +300,10 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       {  // msg = LN(a1 W2^T + b2)
         GemmCore gc = core_blocks(E, 256, 256, w[W_E3(l, E3_EN2_W)], 256, 1, 256);
         ALoadPlain al{F(L.a1[l]), 256, E, 256};
-        EpiLN<ACT_NONE, ACT_NONE, false, false> e;
+        EpiLN<ACT_NONE, ACT_NONE, false> e;
         memset(&e, 0, sizeof e);
         e.M = E; e.bias[0] = w[W_E3(l, E3_EN2_B)]; e.gamma[0] = w[W_E3(l, E3_EN3_G)]; e.beta[0] = w[W_E3(l, E3_EN3_B)];
-        e.eps = 1e-5f; e.C = F(L.msg[l]); e.ldc = 256;
+        e.eps = 1e-5f; e.C = F(L.msg[l]); e.ldc = 256; e.pre_out = S(L.u_m[l]);
         PB("e3_%d.edge_mlp2", l);
         launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
         PE();
@@ -292,8 +311,8 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       {  // wrel = rel * tanh(w2 . SiLU(msg Wc1^T + b) + b2)
         GemmCore gc = core_blocks(E, 256, 128, w[W_E3(l, E3_CN0_W)], 256, 1, 128);
         ALoadPlain al{F(L.msg[l]), 256, E, 256};
-        EpiCoord<false> e{E, w[W_E3(l, E3_CN0_B)], w[W_E3(l, E3_CN2_W)], w[W_E3(l, E3_CN2_B)],
-                          F(L.rel[l]), F(L.wrel[l]), nullptr, nullptr};
+        EpiCoord e{E, w[W_E3(l, E3_CN0_B)], w[W_E3(l, E3_CN2_W)], w[W_E3(l, E3_CN2_B)],
+                          F(L.rel[l]), F(L.wrel[l]), S(L.hc_pre[l]), S(L.cw[l])};
         PB("e3_%d.coord", l);
         launch_gemm<4, W_ALIGNED>(gc, al, e, 1, s);
         PE();
@@ -310,7 +329,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       EpiBiasAct<8, ACT_SILU, false> e;
       memset(&e, 0, sizeof e);
       e.M = N; e.n_valid = 256; e.col_block = 256; e.bias[0] = w[W_E3(l, E3_NN0_B)]; e.C = F(L.hid[l]); e.ldc = 256;
-      e.alpha = 1.0f;
+      e.alpha = 1.0f; e.pre_out = S(L.hid_pre[l]);
       PB("e3_%d.node_mlp1", l);
       launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
       PE();
@@ -318,10 +337,10 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     {  // h = h + LN(hid Wn2^T + b)
       GemmCore gc = core_blocks(N, 256, 256, w[W_E3(l, E3_NN2_W)], 256, 1, 256);
       ALoadPlain al{F(L.hid[l]), 256, N, 256};
-      EpiLN<ACT_NONE, ACT_NONE, true, false> e;
+      EpiLN<ACT_NONE, ACT_NONE, true> e;
       memset(&e, 0, sizeof e);
       e.M = N; e.bias[0] = w[W_E3(l, E3_NN2_B)]; e.gamma[0] = w[W_E3(l, E3_NN3_G)]; e.beta[0] = w[W_E3(l, E3_NN3_B)];
-      e.eps = 1e-5f; e.C = F(L.h_e3[l]); e.ldc = 256; e.resid = h_in; e.ldr = 256;
+      e.eps = 1e-5f; e.C = F(L.h_e3[l]); e.ldc = 256; e.resid = h_in; e.ldr = 256; e.pre_out = S(L.u_h[l]);
       PB("e3_%d.node_mlp2", l);
       launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
       PE();
@@ -345,41 +364,41 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       const size_t lds = (size_t)4 * 2 * 32 * 64 * 4;
       PB("dit%d.attention", l);
       hipLaunchKernelGGL(k_attention<32>, dim3(B), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]),
-                         (float*)nullptr, 32);
+                         S(L.lse[l]), 32);
       PE();
     } else {
       const int mn = max_n <= 64 ? 64 : 128;
       const size_t lds = (size_t)4 * mn * 64 * 4;
       PB("dit%d.attention", l);
       hipLaunchKernelGGL(k_attention<64>, dim3(B * 2), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]),
-                         (float*)nullptr, mn);
+                         S(L.lse[l]), mn);
       PE();
     }
     {  // x1 = x + gate_msa * (att Wo^T + b);  xn2 = LN(x1)(1+scale_mlp)+shift_mlp
       GemmCore gc = core_blocks(N, 256, 256, w[W_DIT(l, DIT_OUT_W)], 256, 1, 256);
       ALoadPlain al{F(L.att[l]), 256, N, 256};
       EpiGate<true> e{N, w[W_DIT(l, DIT_OUT_B)], x_in, F(L.mod[l]), mstride, 512, F(L.mod[l]), 768, 1024,
-                      g->atom_mol, F(L.x1[l]), F(L.xn2[l])};
+                      g->atom_mol, F(L.x1[l]), F(L.xn2[l]), S(L.oproj[l])};
       PB("dit%d.out_proj", l);
       launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
       PE();
     }
     PB("dit%d.ffn_up", l);
     gemm_bias_act<ACT_GELU, false>(F(L.xn2[l]), 256, N, 256, w[W_DIT(l, DIT_FF0_W)], 256, w[W_DIT(l, DIT_FF0_B)], 4,
-                                   F(L.ffh[l]), 1024, nullptr, s);
+                                   F(L.ffh[l]), 1024, nullptr, s, S(L.ffh_pre[l]));
     PE();
     {  // x2 = x1 + gate_mlp * (ffh W3^T + b); next layer's xn1 fused
       GemmCore gc = core_blocks(N, 1024, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1, 256);
       ALoadPlain al{F(L.ffh[l]), 1024, N, 1024};
       if (l < 2) {
         EpiGate<true> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l + 1]), 0, 256,
-                        g->atom_mol, F(L.x2[l]), F(L.xn1[l + 1])};
+                        g->atom_mol, F(L.x2[l]), F(L.xn1[l + 1]), S(L.fproj[l])};
         PB("dit%d.ffn_down", l);
         launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
         PE();
       } else {
         EpiGate<false> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l]), 0, 256,
-                         g->atom_mol, F(L.x2[l]), nullptr};
+                         g->atom_mol, F(L.x2[l]), nullptr, S(L.fproj[l])};
         PB("dit%d.ffn_down", l);
         launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
         PE();
@@ -395,9 +414,9 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     gc.M = N; gc.K = 256; gc.n_valid = 256; gc.ldw = 256;
     gc.W[0] = w[W_HEAD(0, HEAD_W0)]; gc.W[1] = w[W_HEAD(1, HEAD_W0)];
     ALoadPlain al{x_in, 256, N, 256};
-    EpiLN<ACT_GELU, ACT_NONE, false, false> e;
+    EpiLN<ACT_GELU, ACT_NONE, false> e;
     memset(&e, 0, sizeof e);
-    e.M = N; e.eps = 1e-5f; e.C = F(L.yh); e.ldc = 512;
+    e.M = N; e.eps = 1e-5f; e.C = F(L.yh); e.ldc = 512; e.pre_out = S(L.u_head);
     for (int hd = 0; hd < 2; ++hd) {
       e.bias[hd] = w[W_HEAD(hd, HEAD_B0)]; e.gamma[hd] = w[W_HEAD(hd, HEAD_G)]; e.beta[hd] = w[W_HEAD(hd, HEAD_BE)];
     }
@@ -425,9 +444,9 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     hipLaunchKernelGGL(k_mean_pool, dim3(ceil_div(B, 4)), dim3(256), 0, s, x_in, g->mol_ptr, F(L.pooled), B);
     GemmCore gc = core_blocks(B, 256, 256, w[W_HEAD(2, HEAD_W0)], 256, 1, 256);
     ALoadPlain al{F(L.pooled), 256, B, 256};
-    EpiLN<ACT_GELU, ACT_NONE, false, false> e;
+    EpiLN<ACT_GELU, ACT_NONE, false> e;
     memset(&e, 0, sizeof e);
-    e.M = B; e.eps = 1e-5f; e.C = F(L.ph); e.ldc = 256;
+    e.M = B; e.eps = 1e-5f; e.C = F(L.ph); e.ldc = 256; e.pre_out = S(L.u_ph);
     e.bias[0] = w[W_HEAD(2, HEAD_B0)]; e.gamma[0] = w[W_HEAD(2, HEAD_G)]; e.beta[0] = w[W_HEAD(2, HEAD_BE)];
     launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
     hipLaunchKernelGGL(k_head_small<15>, dim3(ceil_div(B, 4)), dim3(256), 0, s, F(L.ph), 256, 0, w[W_HEAD(2, HEAD_W3)],

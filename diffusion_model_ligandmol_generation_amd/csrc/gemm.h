@@ -192,7 +192,8 @@ struct EpiBiasAct {
   const float* bias[8];
   float* C; int ldc;
   float* C2;
-  float alpha;  // scales acc before bias (1.0f normally)
+  float alpha;     // scales acc before bias (1.0f normally)
+  float* pre_out;  // nullable: u = alpha*acc + bias before the activation (kept for backward)
   __device__ __forceinline__ void operator()(f32x16 (&acc)[NT], int row0, int by, int lane) const {
     const int c0 = lane & 31;
     const float* b = bias[by];
@@ -210,9 +211,11 @@ struct EpiBiasAct {
         for (int ct = 0; ct < NT; ++ct) {
           const int col = ct * 32 + c0;
           if (col < n_valid) {
-            const float v = apply_act<ACT>(acc[ct][r] * alpha + bv[ct]);
+            const float u = acc[ct][r] * alpha + bv[ct];
+            const float v = apply_act<ACT>(u);
             const size_t o = (size_t)row * ldc + (size_t)by * col_block + col;
             C[o] = v;
+            if (pre_out != nullptr) pre_out[o] = u;
             if (DUAL_SILU) C2[o] = silu(v);
           }
         }
@@ -222,16 +225,16 @@ struct EpiBiasAct {
 };
 
 // y = post(LN(pre(acc + bias)) * gamma + beta) [+ resid]; each column block is one
-// 256-wide LayerNorm group (NT = 8).  SAVE also stores u = acc + bias, from which the
-// backward pass recomputes the activation and the row statistics.
-template <int PRE_ACT, int POST_ACT, bool RESID, bool SAVE>
+// 256-wide LayerNorm group (NT = 8).  pre_out, if set, also receives u = acc + bias, from
+// which the backward pass recomputes the activation and the row statistics.
+template <int PRE_ACT, int POST_ACT, bool RESID>
 struct EpiLN {
   int M;
   const float* bias[8]; const float* gamma[8]; const float* beta[8];
   float eps;
   float* C; int ldc;
   const float* resid; int ldr;
-  float* pre_out;    // SAVE: [M, ldc] u = acc + bias
+  float* pre_out;    // nullable: [M, ldc] u = acc + bias
   __device__ __forceinline__ void operator()(f32x16 (&acc)[8], int row0, int by, int lane) const {
     const int c0 = lane & 31;
     float bv[8], gv[8], be[8];
@@ -259,7 +262,7 @@ struct EpiLN {
           float y = apply_act<POST_ACT>((v[ct] - mean) * rstd * gv[ct] + be[ct]);
           if (RESID) y += resid[(size_t)row * ldr + (size_t)by * 256 + col];
           C[o] = y;
-          if (SAVE) pre_out[o] = acc[ct][r] + bv[ct];
+          if (pre_out != nullptr) pre_out[o] = acc[ct][r] + bv[ct];
         }
       }
     }

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_edge_geom(
     const float* __restrict__ pos, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
     const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ W2,
     const float* __restrict__ b2, float* __restrict__ rel, float* __restrict__ rbf,
-    float* __restrict__ dist_out, int E) {
+    float* __restrict__ dist_out, float* __restrict__ r1pre_out, int E) {
   __shared__ float sW2[32 * 32];
   __shared__ float sw0[32], sb0[32], sb2[32];
   const int tid = threadIdx.x;
@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void k_edge_geom(
   if (dist_out != nullptr) dist_out[e] = dist;
   float r1[32];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) r1[j] = silu(dist * sw0[j] + sb0[j]);
+  for (int j = 0; j < 32; ++j) {
+    const float pre = dist * sw0[j] + sb0[j];
+    r1[j] = silu(pre);
+    if (r1pre_out != nullptr) r1pre_out[(size_t)e * 32 + j] = pre;
+  }
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     f32x4 o;
@@ -267,12 +271,14 @@ __global__ __launch_bounds__(256) void k_mean_pool(const float* __restrict__ h, 
 // PILOT property encoders, model1.py:341-351: stacked[b, i, :] = W2_i GELU(w0_i p_i + b0_i) + b2_i
 struct PilotEncWeights { const float* w0[8]; const float* b0[8]; const float* W2[8]; const float* b2[8]; };
 __global__ __launch_bounds__(256) void k_pilot_encode(const float* __restrict__ props, PilotEncWeights w,
-                                                      float* __restrict__ stacked) {
+                                                      float* __restrict__ stacked, float* __restrict__ pre_out) {
   __shared__ float hid[8][64];
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < 512; i += 256) {
     const int e = i >> 6, j = i & 63;
-    hid[e][j] = gelu_exact(props[(size_t)b * LD_P + e] * w.w0[e][j] + w.b0[e][j]);
+    const float pre = props[(size_t)b * LD_P + e] * w.w0[e][j] + w.b0[e][j];
+    hid[e][j] = gelu_exact(pre);
+    if (pre_out != nullptr) pre_out[(size_t)b * 512 + i] = pre;
   }
   __syncthreads();
 #pragma unroll 1
@@ -290,14 +296,18 @@ __global__ __launch_bounds__(256) void k_pilot_encode(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_pilot_combine(const float* __restrict__ g, const float* __restrict__ W,
                                                        const float* __restrict__ bias,
                                                        const float* __restrict__ stacked,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, float* __restrict__ z_out,
+                                                       float* __restrict__ w_out) {
   __shared__ float wsm[8];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (size_t)b * 256 + lane * 4);
   for (int o = wave; o < 8; o += 4) {
     const f32x4 wv = *reinterpret_cast<const f32x4*>(W + (size_t)o * 256 + lane * 4);
     const float s = wave_sum((gv[0] * wv[0] + gv[1] * wv[1]) + (gv[2] * wv[2] + gv[3] * wv[3]));
-    if (lane == 0) wsm[o] = softplus(s + bias[o]);
+    if (lane == 0) {
+      wsm[o] = softplus(s + bias[o]);
+      if (z_out != nullptr) z_out[(size_t)b * 8 + o] = s + bias[o];
+    }
   }
   __syncthreads();
   float tot = 0.f;
@@ -307,4 +317,5 @@ __global__ __launch_bounds__(256) void k_pilot_combine(const float* __restrict__
 #pragma unroll
   for (int o = 0; o < 8; ++o) a += stacked[(size_t)b * 2048 + o * 256 + tid] * (wsm[o] / tot);
   out[(size_t)b * 256 + tid] = a;
+  if (w_out != nullptr && tid < 8) w_out[(size_t)b * 8 + tid] = wsm[tid] / tot;
 }

@@ -123,6 +123,68 @@ int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, con
                     const float* properties, int flags, float* atom_pred, float* pos_pred,
                     float* prop_pred, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Score-network backward.  Replaces autograd's reverse pass through model1.py:699-755
+ * (train.py:195).  `fwd_workspace` must be the workspace of a ligdiff_forward call made
+ * with LIGDIFF_FWD_SAVE_FOR_BACKWARD (per-molecule t, same graph / x / pos / properties /
+ * flags).  grads: host array in the weights-table order of device pointers to PRE-ZEROED
+ * fp32 tensors shaped like the weights; parameter gradients are ACCUMULATED into them
+ * (float atomics over row splits, so the last bits vary from run to run).
+ * d_atom [N,119], d_pos [N,3], d_prop [B,15] (NULL = no gradient through prop_pred).
+ * ------------------------------------------------------------------------------- */
+size_t ligdiff_backward_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols);
+int ligdiff_backward(const float* const* weights, float* const* grads, const ligdiff_graph* graph,
+                     const float* x, const float* pos, const float* properties, int flags,
+                     const float* d_atom, const float* d_pos, const float* d_prop,
+                     const void* fwd_workspace, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * EDM noise / loss step.  Replaces ResearchAccurateTrainer._compute_research_exact_loss
+ * (train.py:267-452) around the model call.
+ * ------------------------------------------------------------------------------- */
+
+/* train.py:286-312 with the uniform draws u [B] supplied by the caller:
+ * sigma = (smax^(1/7) + u (smin^(1/7) - smax^(1/7)))^7; coef [B,4] = (c_skip, c_out, c_in,
+ * loss weight) (model1.py:27-45); c_noise [B] = ln(sigma)/4 (the model's time input);
+ * noisy = pos + sigma[mol] noise; pre_pos = noisy * c_in[mol] (the model's pos input). */
+int ligdiff_edm_prepare(const float* u, const float* pos, const float* noise, const int32_t* atom_mol,
+                        int64_t n_atoms, int32_t n_mols, float sigma_min, float sigma_max,
+                        float sigma_data, float* coef, float* c_noise, float* noisy, float* pre_pos,
+                        void* stream);
+
+typedef struct ligdiff_loss_args {
+  const float* pos;         /* [N,3] clean coordinates                                   */
+  const float* noise;       /* [N,3]                                                      */
+  const float* noisy;       /* [N,3] from ligdiff_edm_prepare                             */
+  const float* coef;        /* [B,4] from ligdiff_edm_prepare                             */
+  const float* atom_pred;   /* [N,119]                                                    */
+  const float* pos_pred;    /* [N,3]                                                      */
+  const float* prop_pred;   /* [B,15] (needed when properties != NULL)                    */
+  const float* properties;  /* [B,15] after null-conditioning masking, or NULL            */
+  const int32_t* mol_ptr;   /* [B+1]                                                      */
+  int32_t n_mols;           /* local molecules                                            */
+  int32_t rot_mols;         /* how many LEADING local molecules are among the global      */
+                            /* batch's first two (train.py:642); 0..2                     */
+  int64_t n_atoms_global;   /* atoms / molecules of the whole (all-rank) batch: the       */
+  int64_t n_mols_global;    /* denominators of every mean                                 */
+  void* workspace;          /* ligdiff_loss_workspace_bytes(n_mols)                       */
+} ligdiff_loss_args;
+
+size_t ligdiff_loss_workspace_bytes(int32_t n_mols);
+
+/* sums8 [8] (device): this rank's un-normalised sums of edm_coordinate, edm_preconditioning,
+ * pilot_property, dit_attention, dit_adaptive_norm, e3_coordinate, e3_rotation,
+ * e3_translation (train.py:454-473, :475-498, :603-623, :625-663).  A data-parallel
+ * caller all-reduces (sum) sums8 before ligdiff_loss_finish. */
+int ligdiff_loss_partial(const ligdiff_loss_args* args, float* sums8, void* stream);
+
+/* losses32 (device, 32 floats): [0..7] the eight terms as the reference reports them,
+ * [8] total_loss (train.py:430-437: weighted sum, NaN/Inf terms skipped), [16..23] the
+ * weight each term entered the total with.  Also writes upstream * d(total)/d(prediction)
+ * into d_atom [N,119], d_pos [N,3], d_prop [B,15] (d_prop may be NULL). */
+int ligdiff_loss_finish(const ligdiff_loss_args* args, const float* sums8, float upstream,
+                        float* losses32, float* d_atom, float* d_pos, float* d_prop, void* stream);
+
 /* Measurement hook (no counterpart in the reference): runs `reps` forwards and returns in
  * *mean_ms_host (host pointer) the mean duration, from HIP events recorded on `stream`, of
  * the one launch labelled `label` (e.g. "dit1.ffn_up", "e3_1.aggregate", "dit0.qkv").
