@@ -128,7 +128,8 @@ class ResearchAccurateTrainer:
         n_atoms_g, n_mols_g, mol_off = N, B, 0
         if self.group is not None:
             import torch.distributed as dist
-            cnt = torch.tensor([N, B], device=dev, dtype=torch.int64)
+            cdev = dev if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            cnt = torch.tensor([N, B], device=cdev, dtype=torch.int64)
             allc = [torch.zeros_like(cnt) for _ in range(self.world)]
             dist.all_gather(allc, cnt, group=self.group)
             allc = torch.stack(allc).cpu()
@@ -162,16 +163,8 @@ class ResearchAccurateTrainer:
         rank: it depends only on whether properties are present)."""
         if self.group is None:
             return
-        import torch.distributed as dist
-        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-        if not grads:
-            return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, group=self.group)
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        from .parallel import allreduce_flat
+        allreduce_flat([p.grad for p in self.model.parameters() if p.grad is not None], self.group)
 
     def train_step(self, batch, draws=None):
         """train.py:187-200 for one batch (one shard of the global batch under data parallelism)."""

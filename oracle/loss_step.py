@@ -28,8 +28,17 @@ def _mean_pool(v, batch, B):
 
 
 def loss_step(sd, x, pos, edge_index, batch, u, noise, properties=None, null_rand=None,
-              training=True, max_atoms=100, sigma_min=0.002, sigma_max=80.0, sigma_data=0.5):
-    """Returns (losses dict of 0-dim tensors, aux dict).  B >= 2 (see edm_scalings)."""
+              training=True, max_atoms=100, sigma_min=0.002, sigma_max=80.0, sigma_data=0.5, shard=None):
+    """Returns (losses dict of 0-dim tensors, aux dict).  B >= 2 (see edm_scalings).
+
+    shard=(n_atoms_global, n_mols_global, rot_mols): evaluate ONE data-parallel shard's
+    share of the global-batch loss - every mean divides by the global count and the
+    first-two-molecules distance term only covers this shard's rot_mols leading molecules -
+    so that the shard losses (and their gradients) of all ranks sum to the unsharded
+    result.  Used by the tests of the multi-GPU decomposition; not a reference feature."""
+    if shard is not None:
+        return _loss_step_shard(sd, x, pos, edge_index, batch, u, noise, properties, null_rand, training,
+                                max_atoms, sigma_min, sigma_max, sigma_data, shard)
     B = int(batch.max().item()) + 1
     sigma = edm_sigma_from_u(u, sigma_min, sigma_max)
     c_skip, c_out, c_in, c_noise = edm_scalings(sigma, sigma_data)
@@ -77,3 +86,49 @@ def loss_step(sd, x, pos, edge_index, batch, u, noise, properties=None, null_ran
     aux = {"sigma": sigma, "denoised_pos": den, "atom_pred": atom_pred, "pos_pred": pos_pred,
            "prop_pred": prop_pred}
     return L, aux
+
+
+def _loss_step_shard(sd, x, pos, edge_index, batch, u, noise, properties, null_rand, training, max_atoms,
+                     sigma_min, sigma_max, sigma_data, shard):
+    n_atoms_g, n_mols_g, rot_mols = shard
+    B = int(batch.max().item()) + 1
+    sigma = edm_sigma_from_u(u, sigma_min, sigma_max)
+    # element-wise form of model1.py:27-34 (a shard may hold a single molecule)
+    c_skip = sigma_data ** 2 / (sigma ** 2 + sigma_data ** 2)
+    c_out = sigma * sigma_data / (sigma ** 2 + sigma_data ** 2).sqrt()
+    c_in = 1 / (sigma_data ** 2 + sigma ** 2).sqrt()
+    c_noise = sigma.log() / 4
+    w = edm_loss_weight(sigma, sigma_data)
+    noisy = pos + sigma[batch].unsqueeze(-1) * noise
+    pre = noisy * c_in[batch].unsqueeze(-1)
+    props = None
+    if properties is not None:
+        props = properties.clone()
+        if training:
+            props[null_rand < 0.1] = 0.0
+    atom_pred, pos_pred, prop_pred = score_network_forward(
+        sd, x, pre, edge_index, batch, c_noise, props, max_atoms=max_atoms, pad_to_max_atoms=False)
+    den = c_skip[batch].unsqueeze(-1) * noisy + c_out[batch].unsqueeze(-1) * pos_pred
+    L = {}
+    d = den - pos
+    L["edm_coordinate"] = (d ** 2 * w[batch].unsqueeze(-1)).sum() / (3 * n_atoms_g)
+    L["edm_preconditioning"] = ((d - noise) ** 2).sum() / (3 * n_atoms_g) * 0.1
+    if props is not None:
+        L["pilot_property"] = ((prop_pred - props) ** 2).sum() / (15 * n_mols_g) * 0.2
+    L["dit_attention"] = torch.var(atom_pred, dim=-1).sum() / n_atoms_g * 0.1
+    L["dit_adaptive_norm"] = ((pos_pred.norm(dim=-1) - 1) ** 2).sum() / n_atoms_g * 0.01
+    L["e3_coordinate"] = (d ** 2).sum() / (3 * n_atoms_g)
+    if n_mols_g > 1:
+        rot = torch.tensor(0.0)
+        for b in range(rot_mols):
+            m = batch == b
+            if int(m.sum()) > 1:
+                rot = rot + F.mse_loss(torch.cdist(den[m], den[m]), torch.cdist(pos[m], pos[m])) * 0.1
+        L["e3_rotation"] = rot
+        L["e3_translation"] = (_mean_pool(d, batch, B) ** 2).sum() / (3 * n_mols_g) * 0.01
+    total = torch.tensor(0.0)
+    for k, wt in LOSS_WEIGHTS.items():
+        if k in L:
+            total = total + wt * L[k]
+    L["total_loss"] = total
+    return L, {"denoised_pos": den}

@@ -1,0 +1,83 @@
+"""GPU: data-parallel training step.  Two ranks (gloo, both on cuda:0 - the box has one GPU)
+each take a shard of the fixture batch; after the trainer's loss / backward / gradient
+all-reduce every rank must hold the single-process gradients of the whole batch."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden, seed0_model
+
+pytestmark = pytest.mark.gpu
+
+
+class Bag:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _load():
+    f = golden("loss_step.npz")
+    t = {k: torch.from_numpy(f[k]) for k in ("x", "pos", "edge_index", "batch", "props", "prop_u", "prop_noise",
+                                              "prop_null_rand")}
+    return t
+
+
+def _run(trainer, t, lo, hi):
+    from diffusion_model_ligandmol_generation_amd.parallel import shard_batch
+    xs, ps, es, bs, prs = shard_batch(t["x"], t["pos"], t["edge_index"], t["batch"], lo, hi, t["props"])
+    keep = (t["batch"] >= lo) & (t["batch"] < hi)
+    batch = Bag(x=xs.cuda(), pos=ps.cuda(), edge_index=es.cuda(), batch=bs.cuda(), properties=prs.cuda())
+    draws = {"u": t["prop_u"][lo:hi], "noise": t["prop_noise"][keep], "null_rand": t["prop_null_rand"][lo:hi]}
+    trainer.optimizer.zero_grad()
+    losses = trainer._compute_research_exact_loss(batch, True, draws)
+    losses["total_loss"].backward()
+    trainer._allreduce_gradients()
+    return float(losses["total_loss"]), {n: p.grad.cpu().numpy() for n, p in trainer.model.named_parameters()
+                                         if p.grad is not None}
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from diffusion_model_ligandmol_generation_amd.parallel import shard_ranges
+    from diffusion_model_ligandmol_generation_amd.train import ResearchAccurateTrainer
+    torch.cuda.set_device(0)
+    model = copy.deepcopy(seed0_model()).cuda().train()
+    tr = ResearchAccurateTrainer(model, [], [], [], process_group=dist.group.WORLD)
+    t = _load()
+    sizes = np.bincount(t["batch"].numpy()).tolist()
+    lo, hi = shard_ranges(sizes, world)[rank]
+    loss, grads = _run(tr, t, lo, hi)
+    q.put((rank, loss, grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_step():
+    from diffusion_model_ligandmol_generation_amd.train import ResearchAccurateTrainer
+    t = _load()
+    B = int(t["batch"].max()) + 1
+    tr = ResearchAccurateTrainer(copy.deepcopy(seed0_model()).cuda().train(), [], [], [])
+    ref_loss, ref = _run(tr, t, 0, B)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, loss, grads in res:
+        assert abs(loss - ref_loss) <= 1e-5 * abs(ref_loss)        # every rank reports the GLOBAL loss
+        assert set(grads) == set(ref)
+        for k in ref:
+            assert float(np.abs(grads[k] - ref[k]).max()) <= 1e-4 * float(np.abs(ref[k]).max()) + 1e-9, (rank, k)
