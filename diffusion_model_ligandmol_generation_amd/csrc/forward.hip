@@ -2,7 +2,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "epilogues.h"
+#include "gemm2.h"
 #include "forward.h"
 #include "kernels.h"
 #include "weights.h"
@@ -99,6 +102,24 @@ static void launch_gemm(const GemmCore& g, const AL& al, const EPI& epi, int nb,
   hipLaunchKernelGGL((gemm_rows_kernel<NT, WMODE, AL, EPI>), grid, dim3(256), 0, s, g, al, epi);
 }
 
+// LDS-DMA main loop (gemm2.h) unless LIGDIFF_GEMM_V1 is set in the environment (A/B switch).
+static bool use_gemm2() {
+  static const bool v = getenv("LIGDIFF_GEMM_V1") == nullptr;
+  return v;
+}
+template <int NT, class EPI>
+static void launch_gemm_plain(const GemmCore& g, const float* A, int lda, const EPI& epi, int nb, hipStream_t s) {
+  if (g.M <= 0) return;
+  dim3 grid(ceil_div(g.M, G_BM), nb);
+  if (use_gemm2() && (g.K % G2_BK) == 0 && (lda % 4) == 0 && (g.ldw % 4) == 0) {
+    APtrPlain ap{A, lda};
+    hipLaunchKernelGGL((gemm_rows2_kernel<NT, APtrPlain, EPI>), grid, dim3(256), 0, s, g, ap, epi);
+  } else {
+    ALoadPlain al{A, lda, g.M, g.K};
+    hipLaunchKernelGGL((gemm_rows_kernel<NT, W_ALIGNED, ALoadPlain, EPI>), grid, dim3(256), 0, s, g, al, epi);
+  }
+}
+
 static GemmCore core_blocks(int M, int K, int n_valid, const float* W, int ldw, int nb, int rows_per_block) {
   GemmCore g;
   memset(&g, 0, sizeof g);
@@ -107,18 +128,31 @@ static GemmCore core_blocks(int M, int K, int n_valid, const float* W, int ldw, 
   return g;
 }
 
-// y[M, nb*256] = act(A[M,K] W^T + b)
+// y[M, nb*256] = act(A[M,K] W^T + b).  Plain bias/activation epilogues need no full rows, so
+// they run as 128-column blocks: twice the workgroups with half the accumulators each, which
+// keeps four or more workgroups resident per CU and lets one's epilogue (activation + stores)
+// overlap another's MFMA loop.
 template <int ACT, bool DUAL>
 static void gemm_bias_act(const float* A, int lda, int M, int K, const float* W, int ldw, const float* bias,
                           int nb, float* C, int ldc, float* C2, hipStream_t s, float* pre_out = nullptr) {
+  const int nb4 = nb * 2;
+  if (nb4 <= 8 && use_gemm2()) {
+    GemmCore g = core_blocks(M, K, 128, W, ldw, nb4, 128);
+    EpiBiasAct<4, ACT, DUAL> e;
+    memset(&e, 0, sizeof e);
+    e.M = M; e.n_valid = 128; e.col_block = 128; e.C = C; e.ldc = ldc; e.C2 = C2; e.alpha = 1.0f;
+    e.pre_out = pre_out;
+    for (int i = 0; i < nb4; ++i) e.bias[i] = bias ? bias + (size_t)i * 128 : nullptr;
+    launch_gemm_plain<4>(g, A, lda, e, nb4, s);
+    return;
+  }
   GemmCore g = core_blocks(M, K, 256, W, ldw, nb, 256);
-  ALoadPlain al{A, lda, M, K};
   EpiBiasAct<8, ACT, DUAL> e;
   memset(&e, 0, sizeof e);
   e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = ldc; e.C2 = C2; e.alpha = 1.0f;
   e.pre_out = pre_out;
   for (int i = 0; i < nb; ++i) e.bias[i] = bias ? bias + (size_t)i * 256 : nullptr;
-  launch_gemm<8, W_ALIGNED>(g, al, e, nb, s);
+  launch_gemm_plain<8>(g, A, lda, e, nb, s);
 }
 
 // ------------------------------------------------------------------ workspace layout
@@ -271,14 +305,14 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     {
       GemmCore gc;
       memset(&gc, 0, sizeof gc);
-      gc.M = N; gc.K = 256; gc.n_valid = 256; gc.ldw = 544;
-      gc.W[0] = w[W_E3(l, E3_EN0_W)]; gc.W[1] = w[W_E3(l, E3_EN0_W)] + 256;
-      ALoadPlain al{h_in, 256, N, 256};
-      EpiBiasAct<8, ACT_NONE, false> e;
+      gc.M = N; gc.K = 256; gc.n_valid = 128; gc.ldw = 544;
+      const float* W1 = w[W_E3(l, E3_EN0_W)];
+      gc.W[0] = W1; gc.W[1] = W1 + (size_t)128 * 544; gc.W[2] = W1 + 256; gc.W[3] = W1 + (size_t)128 * 544 + 256;
+      EpiBiasAct<4, ACT_NONE, false> e;
       memset(&e, 0, sizeof e);
-      e.M = N; e.n_valid = 256; e.col_block = 256; e.C = F(L.P[l]); e.ldc = 512; e.alpha = 1.0f;
+      e.M = N; e.n_valid = 128; e.col_block = 128; e.C = F(L.P[l]); e.ldc = 512; e.alpha = 1.0f;
       PB("e3_%d.node_proj", l);
-      launch_gemm<8, W_ALIGNED>(gc, al, e, 2, s);
+      launch_gemm_plain<4>(gc, h_in, 256, e, 4, s);
       PE();
     }
     if (E > 0) {
@@ -291,30 +325,27 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         GemmCore gc;
         memset(&gc, 0, sizeof gc);
         gc.M = E; gc.K = 32; gc.n_valid = 256; gc.ldw = 544; gc.W[0] = w[W_E3(l, E3_EN0_W)] + 512;
-        ALoadPlain al{F(L.rbf[l]), 32, E, 32};
         EpiEdgePre e{E, w[W_E3(l, E3_EN0_B)], F(L.P[l]), g->src, g->dst, F(L.a1[l]), S(L.pre_e[l])};
         PB("e3_%d.edge_pre", l);
-        launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+        launch_gemm_plain<8>(gc, F(L.rbf[l]), 32, e, 1, s);
         PE();
       }
       {  // msg = LN(a1 W2^T + b2)
         GemmCore gc = core_blocks(E, 256, 256, w[W_E3(l, E3_EN2_W)], 256, 1, 256);
-        ALoadPlain al{F(L.a1[l]), 256, E, 256};
         EpiLN<ACT_NONE, ACT_NONE, false> e;
         memset(&e, 0, sizeof e);
         e.M = E; e.bias[0] = w[W_E3(l, E3_EN2_B)]; e.gamma[0] = w[W_E3(l, E3_EN3_G)]; e.beta[0] = w[W_E3(l, E3_EN3_B)];
         e.eps = 1e-5f; e.C = F(L.msg[l]); e.ldc = 256; e.pre_out = S(L.u_m[l]);
         PB("e3_%d.edge_mlp2", l);
-        launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+        launch_gemm_plain<8>(gc, F(L.a1[l]), 256, e, 1, s);
         PE();
       }
       {  // wrel = rel * tanh(w2 . SiLU(msg Wc1^T + b) + b2)
         GemmCore gc = core_blocks(E, 256, 128, w[W_E3(l, E3_CN0_W)], 256, 1, 128);
-        ALoadPlain al{F(L.msg[l]), 256, E, 256};
         EpiCoord e{E, w[W_E3(l, E3_CN0_B)], w[W_E3(l, E3_CN2_W)], w[W_E3(l, E3_CN2_B)],
                           F(L.rel[l]), F(L.wrel[l]), S(L.hc_pre[l]), S(L.cw[l])};
         PB("e3_%d.coord", l);
-        launch_gemm<4, W_ALIGNED>(gc, al, e, 1, s);
+        launch_gemm_plain<4>(gc, F(L.msg[l]), 256, e, 1, s);
         PE();
       }
     }
@@ -326,23 +357,27 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     {  // hid = SiLU([h | agg] Wn1^T + b)
       GemmCore gc = core_blocks(N, 512, 256, w[W_E3(l, E3_NN0_W)], 512, 1, 256);
       ALoadConcat al{h_in, F(L.agg[l]), 256, 256, 256, N, 512};
+      APtrConcat ap{h_in, F(L.agg[l]), 256, 256, 256};
       EpiBiasAct<8, ACT_SILU, false> e;
       memset(&e, 0, sizeof e);
       e.M = N; e.n_valid = 256; e.col_block = 256; e.bias[0] = w[W_E3(l, E3_NN0_B)]; e.C = F(L.hid[l]); e.ldc = 256;
       e.alpha = 1.0f; e.pre_out = S(L.hid_pre[l]);
       PB("e3_%d.node_mlp1", l);
-      launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      if (use_gemm2())
+        hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrConcat, EpiBiasAct<8, ACT_SILU, false>>), dim3(ceil_div(N, G_BM), 1),
+                           dim3(256), 0, s, gc, ap, e);
+      else
+        launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
       PE();
     }
     {  // h = h + LN(hid Wn2^T + b)
       GemmCore gc = core_blocks(N, 256, 256, w[W_E3(l, E3_NN2_W)], 256, 1, 256);
-      ALoadPlain al{F(L.hid[l]), 256, N, 256};
       EpiLN<ACT_NONE, ACT_NONE, true> e;
       memset(&e, 0, sizeof e);
       e.M = N; e.bias[0] = w[W_E3(l, E3_NN2_B)]; e.gamma[0] = w[W_E3(l, E3_NN3_G)]; e.beta[0] = w[W_E3(l, E3_NN3_B)];
       e.eps = 1e-5f; e.C = F(L.h_e3[l]); e.ldc = 256; e.resid = h_in; e.ldr = 256; e.pre_out = S(L.u_h[l]);
       PB("e3_%d.node_mlp2", l);
-      launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      launch_gemm_plain<8>(gc, F(L.hid[l]), 256, e, 1, s);
       PE();
     }
     h_in = F(L.h_e3[l]);
@@ -376,11 +411,10 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     }
     {  // x1 = x + gate_msa * (att Wo^T + b);  xn2 = LN(x1)(1+scale_mlp)+shift_mlp
       GemmCore gc = core_blocks(N, 256, 256, w[W_DIT(l, DIT_OUT_W)], 256, 1, 256);
-      ALoadPlain al{F(L.att[l]), 256, N, 256};
       EpiGate<true> e{N, w[W_DIT(l, DIT_OUT_B)], x_in, F(L.mod[l]), mstride, 512, F(L.mod[l]), 768, 1024,
                       g->atom_mol, F(L.x1[l]), F(L.xn2[l]), S(L.oproj[l])};
       PB("dit%d.out_proj", l);
-      launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+      launch_gemm_plain<8>(gc, F(L.att[l]), 256, e, 1, s);
       PE();
     }
     PB("dit%d.ffn_up", l);
@@ -389,18 +423,17 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     PE();
     {  // x2 = x1 + gate_mlp * (ffh W3^T + b); next layer's xn1 fused
       GemmCore gc = core_blocks(N, 1024, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1, 256);
-      ALoadPlain al{F(L.ffh[l]), 1024, N, 1024};
       if (l < 2) {
         EpiGate<true> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l + 1]), 0, 256,
                         g->atom_mol, F(L.x2[l]), F(L.xn1[l + 1]), S(L.fproj[l])};
         PB("dit%d.ffn_down", l);
-        launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+        launch_gemm_plain<8>(gc, F(L.ffh[l]), 1024, e, 1, s);
         PE();
       } else {
         EpiGate<false> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l]), 0, 256,
                          g->atom_mol, F(L.x2[l]), nullptr, S(L.fproj[l])};
         PB("dit%d.ffn_down", l);
-        launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+        launch_gemm_plain<8>(gc, F(L.ffh[l]), 1024, e, 1, s);
         PE();
       }
     }
@@ -413,7 +446,6 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     memset(&gc, 0, sizeof gc);
     gc.M = N; gc.K = 256; gc.n_valid = 256; gc.ldw = 256;
     gc.W[0] = w[W_HEAD(0, HEAD_W0)]; gc.W[1] = w[W_HEAD(1, HEAD_W0)];
-    ALoadPlain al{x_in, 256, N, 256};
     EpiLN<ACT_GELU, ACT_NONE, false> e;
     memset(&e, 0, sizeof e);
     e.M = N; e.eps = 1e-5f; e.C = F(L.yh); e.ldc = 512; e.pre_out = S(L.u_head);
@@ -421,18 +453,17 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       e.bias[hd] = w[W_HEAD(hd, HEAD_B0)]; e.gamma[hd] = w[W_HEAD(hd, HEAD_G)]; e.beta[hd] = w[W_HEAD(hd, HEAD_BE)];
     }
     PB("head.hidden");
-    launch_gemm<8, W_ALIGNED>(gc, al, e, 2, s);
+    launch_gemm_plain<8>(gc, x_in, 256, e, 2, s);
     PE();
   }
   {  // atom_pred = y_atom W3^T + b   (119 outputs)
     GemmCore gc = core_blocks(N, 256, LD_A, w[W_HEAD(0, HEAD_W3)], 256, 1, 128);
-    ALoadPlain al{F(L.yh), 512, N, 256};
     EpiBiasAct<4, ACT_NONE, false> e;
     memset(&e, 0, sizeof e);
     e.M = N; e.n_valid = LD_A; e.col_block = 0; e.bias[0] = w[W_HEAD(0, HEAD_B3)]; e.C = atom_pred; e.ldc = LD_A;
     e.alpha = 1.0f;
     PB("head.atom");
-    launch_gemm<4, W_ALIGNED>(gc, al, e, 1, s);
+    launch_gemm_plain<4>(gc, F(L.yh), 512, e, 1, s);
     PE();
   }
   PB("head.pos");
@@ -443,12 +474,11 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     if (prop_pred == nullptr) return LIGDIFF_ERR_ARG;
     hipLaunchKernelGGL(k_mean_pool, dim3(ceil_div(B, 4)), dim3(256), 0, s, x_in, g->mol_ptr, F(L.pooled), B);
     GemmCore gc = core_blocks(B, 256, 256, w[W_HEAD(2, HEAD_W0)], 256, 1, 256);
-    ALoadPlain al{F(L.pooled), 256, B, 256};
     EpiLN<ACT_GELU, ACT_NONE, false> e;
     memset(&e, 0, sizeof e);
     e.M = B; e.eps = 1e-5f; e.C = F(L.ph); e.ldc = 256; e.pre_out = S(L.u_ph);
     e.bias[0] = w[W_HEAD(2, HEAD_B0)]; e.gamma[0] = w[W_HEAD(2, HEAD_G)]; e.beta[0] = w[W_HEAD(2, HEAD_BE)];
-    launch_gemm<8, W_ALIGNED>(gc, al, e, 1, s);
+    launch_gemm_plain<8>(gc, F(L.pooled), 256, e, 1, s);
     hipLaunchKernelGGL(k_head_small<15>, dim3(ceil_div(B, 4)), dim3(256), 0, s, F(L.ph), 256, 0, w[W_HEAD(2, HEAD_W3)],
                        w[W_HEAD(2, HEAD_B3)], (const float*)nullptr, prop_pred, B);
   }

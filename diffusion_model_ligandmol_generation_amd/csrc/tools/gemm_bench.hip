@@ -1,0 +1,123 @@
+// Stand-alone timing harness for the row-slab GEMM kernels (developer tool, not part of the
+// library).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gemm_bench gemm_bench.hip
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../epilogues.h"
+#include "../gemm2.h"
+
+struct EpiNull {  // keeps the accumulators alive with one store per lane
+  float* C;
+  __device__ __forceinline__ void operator()(f32x16 (&acc)[8], int row0, int by, int lane) const {
+    float s = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[ct][r];
+    if (s == 123.456f) C[row0 + lane] = s;
+  }
+};
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <class F>
+static float time_it(F f, int reps) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) f();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a, 0));
+  for (int i = 0; i < reps; ++i) f();
+  CK(hipEventRecord(b, 0));
+  CK(hipEventSynchronize(b));
+  float ms;
+  CK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
+int main() {
+  const int M = 29696, E = 63488;
+  std::vector<float> h((size_t)E * 1024);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+  float *A, *W, *C, *C2, *bias, *mod;
+  int* mol;
+  CK(hipMalloc(&A, (size_t)E * 1024 * 4)); CK(hipMalloc(&W, 1024 * 1024 * 4)); CK(hipMalloc(&C, (size_t)E * 1024 * 4));
+  CK(hipMalloc(&C2, (size_t)E * 1024 * 4)); CK(hipMalloc(&bias, 4096 * 4)); CK(hipMalloc(&mod, 1536 * 4));
+  CK(hipMalloc(&mol, E * 4));
+  CK(hipMemcpy(A, h.data(), (size_t)E * 1024 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, h.data(), 1024 * 1024 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(bias, h.data(), 4096 * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(mod, h.data(), 1536 * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(mol, 0, E * 4));
+
+  auto core = [&](int Mr, int K, int nb, int ldw) {
+    GemmCore g; memset(&g, 0, sizeof g);
+    g.M = Mr; g.K = K; g.n_valid = 256; g.ldw = ldw;
+    for (int i = 0; i < nb; ++i) g.W[i] = W + (size_t)i * 256 * ldw;
+    return g;
+  };
+  auto report = [&](const char* name, float ms, double flops) {
+    printf("%-44s %8.1f us  %6.1f TFLOP/s\n", name, ms * 1e3, flops / (ms * 1e-3) / 1e12);
+  };
+  {  // FFN up: K=256, N=1024, GELU
+    GemmCore g = core(M, 256, 4, 256);
+    APtrPlain ap{A, 256};
+    EpiBiasAct<8, ACT_GELU, false> e; memset(&e, 0, sizeof e);
+    e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = 1024; e.alpha = 1.f;
+    for (int i = 0; i < 4; ++i) e.bias[i] = bias + i * 256;
+    float ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrPlain, EpiBiasAct<8, ACT_GELU, false>>), dim3(232, 4), dim3(256), 0, 0, g, ap, e); }, 20);
+    report("v2 ffn_up  M29696 K256 N1024 bias+GELU", ms, 2.0 * M * 256 * 1024);
+    EpiBiasAct<8, ACT_NONE, false> e0; memcpy(&e0, &e, sizeof e);
+    ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrPlain, EpiBiasAct<8, ACT_NONE, false>>), dim3(232, 4), dim3(256), 0, 0, g, ap, e0); }, 20);
+    report("v2         M29696 K256 N1024 bias only", ms, 2.0 * M * 256 * 1024);
+    EpiNull en{C};
+    ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrPlain, EpiNull>), dim3(232, 4), dim3(256), 0, 0, g, ap, en); }, 20);
+    report("v2         M29696 K256 N1024 no epilogue", ms, 2.0 * M * 256 * 1024);
+    {  // 128-column blocks: twice the workgroups, half the accumulators
+      GemmCore g4; memset(&g4, 0, sizeof g4);
+      g4.M = M; g4.K = 256; g4.n_valid = 128; g4.ldw = 256;
+      for (int i = 0; i < 8; ++i) g4.W[i] = W + (size_t)i * 128 * 256;
+      EpiBiasAct<4, ACT_GELU, false> e4; memset(&e4, 0, sizeof e4);
+      e4.M = M; e4.n_valid = 128; e4.col_block = 128; e4.C = C; e4.ldc = 1024; e4.alpha = 1.f;
+      for (int i = 0; i < 8; ++i) e4.bias[i] = bias + i * 128;
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<4, APtrPlain, EpiBiasAct<4, ACT_GELU, false>>), dim3(232, 8), dim3(256), 0, 0, g4, ap, e4); }, 20);
+      report("v2 NT=4    M29696 K256 N1024 bias+GELU", ms, 2.0 * M * 256 * 1024);
+      EpiBiasAct<4, ACT_NONE, false> e40; memcpy(&e40, &e4, sizeof e4);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<4, APtrPlain, EpiBiasAct<4, ACT_NONE, false>>), dim3(232, 8), dim3(256), 0, 0, g4, ap, e40); }, 20);
+      report("v2 NT=4    M29696 K256 N1024 bias only", ms, 2.0 * M * 256 * 1024);
+    }
+    ALoadPlain al{A, 256, M, 256};
+    ms = time_it([&] { hipLaunchKernelGGL((gemm_rows_kernel<8, W_ALIGNED, ALoadPlain, EpiBiasAct<8, ACT_GELU, false>>), dim3(232, 4), dim3(256), 0, 0, g, al, e); }, 20);
+    report("v1 ffn_up  M29696 K256 N1024 bias+GELU", ms, 2.0 * M * 256 * 1024);
+    ms = time_it([&] { hipLaunchKernelGGL((gemm_rows_kernel<8, W_ALIGNED, ALoadPlain, EpiNull>), dim3(232, 4), dim3(256), 0, 0, g, al, en); }, 20);
+    report("v1         M29696 K256 N1024 no epilogue", ms, 2.0 * M * 256 * 1024);
+  }
+  {  // FFN down: K=1024, N=256, gated residual + modulated LN
+    GemmCore g = core(M, 1024, 1, 1024);
+    APtrPlain ap{A, 1024};
+    EpiGate<true> e{M, bias, C2, mod, 0, 0, mod, 256, 512, mol, C, C + (size_t)M * 256, nullptr};
+    float ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrPlain, EpiGate<true>>), dim3(232, 1), dim3(256), 0, 0, g, ap, e); }, 20);
+    report("v2 ffn_down M29696 K1024 N256 gate+LNmod", ms, 2.0 * M * 1024 * 256);
+    EpiNull en{C};
+    ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrPlain, EpiNull>), dim3(232, 1), dim3(256), 0, 0, g, ap, en); }, 20);
+    report("v2          M29696 K1024 N256 no epilogue", ms, 2.0 * M * 1024 * 256);
+  }
+  {  // edge MLP 2: M=E, K=256, N=256, LN
+    GemmCore g = core(E, 256, 1, 256);
+    APtrPlain ap{A, 256};
+    EpiLN<ACT_NONE, ACT_NONE, false> e; memset(&e, 0, sizeof e);
+    e.M = E; e.bias[0] = bias; e.gamma[0] = bias + 256; e.beta[0] = bias + 512; e.eps = 1e-5f; e.C = C; e.ldc = 256;
+    float ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>>), dim3(496, 1), dim3(256), 0, 0, g, ap, e); }, 20);
+    report("v2 edge_mlp2 M63488 K256 N256 LN", ms, 2.0 * E * 256 * 256);
+    EpiNull en{C};
+    ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrPlain, EpiNull>), dim3(496, 1), dim3(256), 0, 0, g, ap, en); }, 20);
+    report("v2           M63488 K256 N256 no epilogue", ms, 2.0 * E * 256 * 256);
+    GemmCore g2 = core(M, 256, 1, 256);
+    e.M = M;
+    ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>>), dim3(232, 1), dim3(256), 0, 0, g2, ap, e); }, 20);
+    report("v2 node_mlp2 M29696 K256 N256 LN", ms, 2.0 * M * 256 * 256);
+  }
+  return 0;
+}
