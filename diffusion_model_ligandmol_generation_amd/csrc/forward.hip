@@ -395,20 +395,21 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     gemm_bias_act<ACT_NONE, false>(F(L.xn1[l]), 256, N, 256, w[W_DIT(l, DIT_INP_W)], 256, w[W_DIT(l, DIT_INP_B)], 3,
                                    F(L.qkv[l]), 768, nullptr, s);
     PE();
-    if (max_n <= 32) {
-      const size_t lds = (size_t)4 * 2 * 32 * 64 * 4;
-      PB("dit%d.attention", l);
-      hipLaunchKernelGGL(k_attention<32>, dim3(B), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]),
-                         S(L.lse[l]), 32);
-      PE();
-    } else {
-      const int mn = max_n <= 64 ? 64 : 128;
-      const size_t lds = (size_t)4 * mn * 64 * 4;
-      PB("dit%d.attention", l);
-      hipLaunchKernelGGL(k_attention<64>, dim3(B * 2), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]),
-                         S(L.lse[l]), mn);
-      PE();
+    PB("dit%d.attention", l);
+    {
+      const int tk = (max_n + 31) / 32;
+      const size_t lds = (size_t)4 * 2 * (tk * 32) * 33 * 4;
+      const int blocks = ceil_div((long)B * 8 * tk, 4);
+      if (tk == 1)
+        hipLaunchKernelGGL(k_attention_mfma<1>, dim3(blocks), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]), S(L.lse[l]), B);
+      else if (tk == 2)
+        hipLaunchKernelGGL(k_attention_mfma<2>, dim3(blocks), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]), S(L.lse[l]), B);
+      else if (tk == 3)
+        hipLaunchKernelGGL(k_attention_mfma<3>, dim3(blocks), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]), S(L.lse[l]), B);
+      else
+        hipLaunchKernelGGL(k_attention_mfma<4>, dim3(blocks), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]), S(L.lse[l]), B);
     }
+    PE();
     {  // x1 = x + gate_msa * (att Wo^T + b);  xn2 = LN(x1)(1+scale_mlp)+shift_mlp
       GemmCore gc = core_blocks(N, 256, 256, w[W_DIT(l, DIT_OUT_W)], 256, 1, 256);
       EpiGate<true> e{N, w[W_DIT(l, DIT_OUT_B)], x_in, F(L.mod[l]), mstride, 512, F(L.mod[l]), 768, 1024,

@@ -5,6 +5,9 @@
 #pragma once
 #include "common.h"
 
+// accumulator row of register r in lane half h of a 32x32 MFMA tile
+#define G_ROW_ATT(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
+
 // Fourier features, model1.py:686-697.  freqs[128] is computed on the host with the
 // reference's own expression; t is the per-molecule value or one device-side step index.
 __global__ void k_fourier(const float* __restrict__ t, const int32_t* __restrict__ t_index,
@@ -230,6 +233,109 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 #pragma unroll
     for (int d = 0; d < 8; ++d) *reinterpret_cast<f32x4*>(op + d * 4) = o[d] * inv;
     if (lse_out != nullptr) lse_out[(size_t)(a0 + qi) * 8 + head0 + hh] = m + logf(l);
+  }
+}
+
+// MFMA form of the same attention (fp32 v_mfma_f32_32x32x2_f32, exact fp32 dot products).
+// One wave per (molecule, head, 32-query tile).  Scores are computed TRANSPOSED,
+//   S^T[j, i] = sum_d K[j, d] (scale Q[i, d]),
+// so a lane owns ONE query i (accumulator column) and holds 16 of every 32 keys in its
+// registers: the softmax max / sum are in-lane plus one cross-half shuffle.  The
+// probability tile is then fed straight back as the B operand of
+//   O^T[d, i] = sum_j V[j, d] P^T[j, i]
+// (accumulator register r of lane half h is key j = (r&3) + 8(r>>2) + 4h, and the A operand
+// fetches V[j(r,h), d] to match), so P never leaves registers.  K and V of the head sit in
+// LDS ([n][33] floats: conflict-free column reads); keys beyond n get weight 0, queries
+// beyond n are not stored.  TK = number of 32-key tiles (n <= 32 TK).
+template <int TK>
+__global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict__ qkv,
+                                                        const int32_t* __restrict__ mol_ptr,
+                                                        float* __restrict__ out, float* __restrict__ lse_out,
+                                                        int n_mols) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NP = TK * 32;          // padded key count
+  constexpr int ITEMS = 8 * TK;        // (head, query tile) items per molecule
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = blockIdx.x * 4 + wave;
+  const int mol = item / ITEMS, rem = item % ITEMS;
+  const int head = rem / TK, qt = rem % TK;
+  float* sk = smem + (size_t)wave * (2 * NP * 33);
+  float* sv = sk + NP * 33;
+  int a0 = 0, n = 0;
+  if (mol < n_mols) { a0 = mol_ptr[mol]; n = mol_ptr[mol + 1] - a0; }
+  const bool active = (mol < n_mols) && (qt * 32 < n);
+  if (active) {
+    for (int i = lane; i < NP * 8; i += 64) {   // stage K, V rows of this head (zeros beyond n)
+      const int j = i >> 3, c = (i & 7) * 4;
+      f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (j < n) {
+        const float* r = qkv + (size_t)(a0 + j) * 768 + head * 32 + c;
+        kk = *reinterpret_cast<const f32x4*>(r + 256);
+        vv = *reinterpret_cast<const f32x4*>(r + 512);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sk[j * 33 + c + e] = kk[e]; sv[j * 33 + c + e] = vv[e]; }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  const int fi = lane & 31, h = lane >> 5;
+  const int qi = qt * 32 + fi;                    // this lane's query (both halves share it)
+  const float scale = 0.17677669529663687f;       // 1/sqrt(32)
+  float q[16];                                    // Q[qi, 2s + h] * scale, s = 0..15
+  {
+    const int qr = qi < n ? qi : n - 1;
+    const float* qp = qkv + (size_t)(a0 + qr) * 768 + head * 32;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) q[s] = qp[2 * s + h] * scale;
+  }
+  f32x16 sc[TK];
+#pragma unroll
+  for (int t = 0; t < TK; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)    // A = K[t*32 + fi, 2s + h], B = q
+      sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[(t * 32 + fi) * 33 + 2 * s + h], q[s], sc[t], 0, 0, 0);
+  }
+  // softmax over keys: lane (i, h) holds keys j = t*32 + G_ROW(r, lane)
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = t * 32 + G_ROW_ATT(r, h);
+      sc[t][r] = j < n ? sc[t][r] : -INFINITY;
+      m = fmaxf(m, sc[t][r]);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(sc[t][r] - m);       // exp(-inf) = 0 for padded keys
+      sc[t][r] = p;
+      l += p;
+    }
+  l += __shfl_xor(l, 32);
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)   // A = V[j(r,h), d = fi], B = P^T[j(r,h), i]
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[(t * 32 + G_ROW_ATT(r, h)) * 33 + fi], sc[t][r], o, 0, 0, 0);
+  if (qi < n) {
+    const float inv = 1.0f / l;
+    float* op = out + (size_t)(a0 + qi) * 256 + head * 32;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {   // registers 4g..4g+3 are d = 8g + 4h + (0..3)
+      f32x4 v = {o[gq * 4 + 0] * inv, o[gq * 4 + 1] * inv, o[gq * 4 + 2] * inv, o[gq * 4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + gq * 8 + h * 4) = v;
+    }
+    if (lse_out != nullptr && h == 0) lse_out[(size_t)(a0 + qi) * 8 + head] = m + logf(l);
   }
 }
 

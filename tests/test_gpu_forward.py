@@ -71,7 +71,7 @@ def _random_batch(sizes, seed, fully_connected=False):
 
 
 @pytest.mark.parametrize("sizes,fc", [([29] * 64, False), ([5, 6, 15, 16, 2, 31, 33, 64], False),
-                                      ([65, 100, 40], True), ([3], False)])
+                                      ([65, 100, 40], True), ([70, 96, 12], False), ([3], False)])
 def test_forward_matches_oracle_ragged(sizes, fc):
     import copy
     max_atoms = 128 if max(sizes) > 100 or fc else 100
