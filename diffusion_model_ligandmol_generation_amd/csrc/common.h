@@ -55,14 +55,26 @@ __device__ __forceinline__ float silu_grad(float v) {
   return s * (1.0f + v * (1.0f - s));
 }
 
-// Sum over the 32 lanes of each half-wave (lanes 0-31 and 32-63 reduce separately).
+// Lane exchanges on the VALU data-parallel-primitive path (no LDS crossbar traffic).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// v + (v of lane ^ 16): v_permlane16_swap exchanges the odd 16-lane rows of its first
+// operand with the even rows of its second, so swapping a value with its own copy leaves
+// {row0,row0,row2,row2} and {row1,row1,row3,row3}.
+__device__ __forceinline__ float add_xor16(float v) {
+  const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+// Sum over the 32 lanes of each half-wave (lanes 0-31 and 32-63 reduce separately); every
+// lane of the half receives the total.
 __device__ __forceinline__ float half_wave_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
+  v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);   // row_half_mirror: lane i <-> 7-i of each 8
+  v += dpp_move<0x140>(v);   // row_mirror: lane i <-> 15-i of each 16
+  return add_xor16(v);
 }
 __device__ __forceinline__ float wave_sum(float v) {
   v += __shfl_xor(v, 32);
