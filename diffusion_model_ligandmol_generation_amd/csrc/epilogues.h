@@ -114,6 +114,59 @@ struct EpiGate {
       }
     }
   }
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
+    const int c0 = lane & 31;
+    const int cb = half * 128 + c0;
+    float bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = bias[cb + ct * 32];
+    float mean[16], q2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      const int rr = row < M ? row : M - 1;
+      const float* g = mod + (size_t)atom_mol[rr] * mod_stride + gate_off;
+      float s = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const int col = cb + ct * 32;
+        const float pr = acc[ct][r] + bv[ct];
+        if (proj_out != nullptr && row < M) proj_out[(size_t)row * 256 + col] = pr;
+        acc[ct][r] = resid[(size_t)rr * 256 + col] + g[col] * pr;
+        s += acc[ct][r];
+        if (row < M) X[(size_t)row * 256 + col] = acc[ct][r];
+      }
+      if (LNMOD) {
+        mean[r] = half_wave_sum(s) * (1.0f / 128.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { const float d = acc[ct][r] - mean[r]; q += d * d; }
+        q2[r] = half_wave_sum(q);
+      }
+    }
+    if (LNMOD) {
+      mb.put(0, mean); mb.put(1, q2);
+      __syncthreads();
+      float pmean[16], pq2[16];
+      mb.get_partner(0, pmean); mb.get_partner(1, pq2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + G_ROW(r, lane);
+        const float dm = mean[r] - pmean[r];
+        const float mu = 0.5f * (mean[r] + pmean[r]);
+        const float rstd = 1.0f / sqrtf((q2[r] + pq2[r] + 64.0f * dm * dm) * (1.0f / 256.0f) + 1e-6f);
+        if (row < M) {
+          const float* m2 = mod2 + (size_t)atom_mol[row] * mod_stride;
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            const int col = cb + ct * 32;
+            XN[(size_t)row * 256 + col] = ((acc[ct][r] - mu) * rstd) * (1.0f + m2[scale_off + col]) + m2[shift_off + col];
+          }
+        }
+      }
+    }
+  }
 };
 
 // First edge-MLP layer split by operand, model1.py:96-97 (Linear 544->256, SiLU):
@@ -141,6 +194,28 @@ struct EpiEdgePre {
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
           const int col = ct * 32 + c0;
+          const float v = (pa[col] + pb[col]) + (acc[ct][r] + bv[ct]);
+          A1[(size_t)row * 256 + col] = silu(v);
+          if (pre_out != nullptr) pre_out[(size_t)row * 256 + col] = v;
+        }
+      }
+    }
+  }
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
+    const int cb = half * 128 + (lane & 31);
+    float bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = b1[cb + ct * 32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      if (row < M) {
+        const float* pa = P + (size_t)src[row] * 512;
+        const float* pb = P + (size_t)dst[row] * 512 + 256;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int col = cb + ct * 32;
           const float v = (pa[col] + pb[col]) + (acc[ct][r] + bv[ct]);
           A1[(size_t)row * 256 + col] = silu(v);
           if (pre_out != nullptr) pre_out[(size_t)row * 256 + col] = v;

@@ -5,7 +5,7 @@
 #include <stdlib.h>
 
 #include "epilogues.h"
-#include "gemm2.h"
+#include "gemm3.h"
 #include "forward.h"
 #include "kernels.h"
 #include "weights.h"
@@ -107,10 +107,26 @@ static bool use_gemm2() {
   static const bool v = getenv("LIGDIFF_GEMM_V1") == nullptr;
   return v;
 }
+// Eight-wave column-split kernel (gemm3.h) for 256-column blocks unless LIGDIFF_GEMM_NOCS is set.
+static bool use_cs() {
+  static const bool v = getenv("LIGDIFF_GEMM_NOCS") == nullptr && getenv("LIGDIFF_GEMM_V1") == nullptr;
+  return v;
+}
+template <class AP, class EPI>
+static void launch_gemm_cs(const GemmCore& g, const AP& ap, const EPI& epi, int nb, hipStream_t s) {
+  if (g.M <= 0) return;
+  hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);
+}
 template <int NT, class EPI>
 static void launch_gemm_plain(const GemmCore& g, const float* A, int lda, const EPI& epi, int nb, hipStream_t s) {
   if (g.M <= 0) return;
   dim3 grid(ceil_div(g.M, G_BM), nb);
+  if constexpr (NT == 8) {
+    if (use_cs() && (g.K % G2_BK) == 0 && (lda % 4) == 0 && (g.ldw % 4) == 0 && g.n_valid == 256) {
+      launch_gemm_cs(g, APtrPlain{A, lda}, epi, nb, s);
+      return;
+    }
+  }
   if (use_gemm2() && (g.K % G2_BK) == 0 && (lda % 4) == 0 && (g.ldw % 4) == 0) {
     APtrPlain ap{A, lda};
     hipLaunchKernelGGL((gemm_rows2_kernel<NT, APtrPlain, EPI>), grid, dim3(256), 0, s, g, ap, epi);
@@ -136,6 +152,16 @@ template <int ACT, bool DUAL>
 static void gemm_bias_act(const float* A, int lda, int M, int K, const float* W, int ldw, const float* bias,
                           int nb, float* C, int ldc, float* C2, hipStream_t s, float* pre_out = nullptr) {
   const int nb4 = nb * 2;
+  if (use_cs() && (K % G2_BK) == 0 && (lda % 4) == 0 && (ldw % 4) == 0) {
+    GemmCore g = core_blocks(M, K, 256, W, ldw, nb, 256);
+    EpiBiasAct<8, ACT, DUAL> e;
+    memset(&e, 0, sizeof e);
+    e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = ldc; e.C2 = C2; e.alpha = 1.0f;
+    e.pre_out = pre_out;
+    for (int i = 0; i < nb; ++i) e.bias[i] = bias ? bias + (size_t)i * 256 : nullptr;
+    launch_gemm_cs(g, APtrPlain{A, lda}, e, nb, s);
+    return;
+  }
   if (nb4 <= 8 && use_gemm2()) {
     GemmCore g = core_blocks(M, K, 128, W, ldw, nb4, 128);
     EpiBiasAct<4, ACT, DUAL> e;
@@ -312,7 +338,17 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       memset(&e, 0, sizeof e);
       e.M = N; e.n_valid = 128; e.col_block = 128; e.C = F(L.P[l]); e.ldc = 512; e.alpha = 1.0f;
       PB("e3_%d.node_proj", l);
-      launch_gemm_plain<4>(gc, h_in, 256, e, 4, s);
+      if (use_cs()) {
+        GemmCore g2;
+        memset(&g2, 0, sizeof g2);
+        g2.M = N; g2.K = 256; g2.n_valid = 256; g2.ldw = 544; g2.W[0] = W1; g2.W[1] = W1 + 256;
+        EpiBiasAct<8, ACT_NONE, false> e2;
+        memset(&e2, 0, sizeof e2);
+        e2.M = N; e2.n_valid = 256; e2.col_block = 256; e2.C = F(L.P[l]); e2.ldc = 512; e2.alpha = 1.0f;
+        launch_gemm_cs(g2, APtrPlain{h_in, 256}, e2, 2, s);
+      } else {
+        launch_gemm_plain<4>(gc, h_in, 256, e, 4, s);
+      }
       PE();
     }
     if (E > 0) {
@@ -363,7 +399,9 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       e.M = N; e.n_valid = 256; e.col_block = 256; e.bias[0] = w[W_E3(l, E3_NN0_B)]; e.C = F(L.hid[l]); e.ldc = 256;
       e.alpha = 1.0f; e.pre_out = S(L.hid_pre[l]);
       PB("e3_%d.node_mlp1", l);
-      if (use_gemm2())
+      if (use_cs())
+        launch_gemm_cs(gc, ap, e, 1, s);
+      else if (use_gemm2())
         hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrConcat, EpiBiasAct<8, ACT_SILU, false>>), dim3(ceil_div(N, G_BM), 1),
                            dim3(256), 0, s, gc, ap, e);
       else

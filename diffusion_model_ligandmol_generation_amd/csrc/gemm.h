@@ -176,6 +176,11 @@ __global__ __launch_bounds__(256, 2) void gemm_rows_kernel(GemmCore g, AL al, EP
 }
 
 // ------------------------------------------------------------------------ epilogues
+// Every epilogue has two entry points: operator() for kernels whose wave holds all columns
+// of its rows (NT accumulators), and cs() for the column-split kernel of gemm3.h, where the
+// wave holds columns [128 half, 128 half + 128) as four accumulators and per-row partial
+// results cross to the partner wave through the HalfMailbox.
+struct HalfMailbox;
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {
@@ -222,6 +227,29 @@ struct EpiBiasAct {
       }
     }
   }
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
+    const int c0 = lane & 31;
+    const float* b = bias[by];
+    float bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = b != nullptr ? b[half * 128 + ct * 32 + c0] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      if (row < M) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const float u = acc[ct][r] * alpha + bv[ct];
+          const float v = apply_act<ACT>(u);
+          const size_t o = (size_t)row * ldc + (size_t)by * col_block + half * 128 + ct * 32 + c0;
+          C[o] = v;
+          if (pre_out != nullptr) pre_out[o] = u;
+          if (DUAL_SILU) C2[o] = silu(v);
+        }
+      }
+    }
+  }
 };
 
 // y = post(LN(pre(acc + bias)) * gamma + beta) [+ resid]; each column block is one
@@ -263,6 +291,56 @@ struct EpiLN {
           if (RESID) y += resid[(size_t)row * ldr + (size_t)by * 256 + col];
           C[o] = y;
           if (pre_out != nullptr) pre_out[o] = acc[ct][r] + bv[ct];
+        }
+      }
+    }
+  }
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
+    const int c0 = lane & 31;
+    const int cb = by * 256 + half * 128;
+    float bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = bias[by][half * 128 + ct * 32 + c0];
+    float mean[16], m2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      float s = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float u = acc[ct][r] + bv[ct];
+        if (pre_out != nullptr && row < M) pre_out[(size_t)row * ldc + cb + ct * 32 + c0] = u;
+        acc[ct][r] = apply_act<PRE_ACT>(u);
+        s += acc[ct][r];
+      }
+      mean[r] = half_wave_sum(s) * (1.0f / 128.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) { const float d = acc[ct][r] - mean[r]; q += d * d; }
+      m2[r] = half_wave_sum(q);
+    }
+    mb.put(0, mean); mb.put(1, m2);
+    __syncthreads();
+    float pmean[16], pm2[16];
+    mb.get_partner(0, pmean); mb.get_partner(1, pm2);
+    float gv[4], be[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { gv[ct] = gamma[by][half * 128 + ct * 32 + c0]; be[ct] = beta[by][half * 128 + ct * 32 + c0]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      const float dm = mean[r] - pmean[r];
+      const float mu = 0.5f * (mean[r] + pmean[r]);
+      const float var = (m2[r] + pm2[r] + 64.0f * dm * dm) * (1.0f / 256.0f);
+      const float rstd = 1.0f / sqrtf(var + eps);
+      if (row < M) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const size_t o = (size_t)row * ldc + cb + ct * 32 + c0;
+          float y = apply_act<POST_ACT>((acc[ct][r] - mu) * rstd * gv[ct] + be[ct]);
+          if (RESID) y += resid[(size_t)row * ldr + cb + ct * 32 + c0];
+          C[o] = y;
         }
       }
     }

@@ -6,7 +6,7 @@
 #include <vector>
 
 #include "../epilogues.h"
-#include "../gemm2.h"
+#include "../gemm3.h"
 
 struct EpiNull {  // keeps the accumulators alive with one store per lane
   float* C;
@@ -14,6 +14,15 @@ struct EpiNull {  // keeps the accumulators alive with one store per lane
     float s = 0.f;
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[ct][r];
+    if (s == 123.456f) C[row0 + lane] = s;
+  }
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
+    float s = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s += acc[ct][r];
     if (s == 123.456f) C[row0 + lane] = s;
@@ -118,6 +127,49 @@ int main() {
     e.M = M;
     ms = time_it([&] { hipLaunchKernelGGL((gemm_rows2_kernel<8, APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>>), dim3(232, 1), dim3(256), 0, 0, g2, ap, e); }, 20);
     report("v2 node_mlp2 M29696 K256 N256 LN", ms, 2.0 * M * 256 * 256);
+  }
+  printf("--- column-split 8-wave kernel\n");
+  {
+    EpiNull en{C};
+    {
+      GemmCore g = core(M, 256, 4, 256);
+      APtrPlain ap{A, 256};
+      EpiBiasAct<8, ACT_GELU, false> e; memset(&e, 0, sizeof e);
+      e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = 1024; e.alpha = 1.f;
+      for (int i = 0; i < 4; ++i) e.bias[i] = bias + i * 256;
+      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiBiasAct<8, ACT_GELU, false>>), dim3(232, 4), dim3(512), 0, 0, g, ap, e); }, 20);
+      report("cs ffn_up  M29696 K256 N1024 bias+GELU", ms, 2.0 * M * 256 * 1024);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiNull>), dim3(232, 4), dim3(512), 0, 0, g, ap, en); }, 20);
+      report("cs         M29696 K256 N1024 no epilogue", ms, 2.0 * M * 256 * 1024);
+      GemmCore g3 = core(M, 256, 3, 256);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiNull>), dim3(232, 3), dim3(512), 0, 0, g3, ap, en); }, 20);
+      report("cs qkv     M29696 K256 N768 no epilogue", ms, 2.0 * M * 256 * 768);
+    }
+    {
+      GemmCore g = core(M, 1024, 1, 1024);
+      APtrPlain ap{A, 1024};
+      EpiGate<true> e{M, bias, C2, mod, 0, 0, mod, 256, 512, mol, C, C + (size_t)M * 256, nullptr};
+      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiGate<true>>), dim3(232, 1), dim3(512), 0, 0, g, ap, e); }, 20);
+      report("cs ffn_down M29696 K1024 N256 gate+LNmod", ms, 2.0 * M * 1024 * 256);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiNull>), dim3(232, 1), dim3(512), 0, 0, g, ap, en); }, 20);
+      report("cs          M29696 K1024 N256 no epilogue", ms, 2.0 * M * 1024 * 256);
+    }
+    {
+      GemmCore g = core(E, 256, 1, 256);
+      APtrPlain ap{A, 256};
+      EpiLN<ACT_NONE, ACT_NONE, false> e; memset(&e, 0, sizeof e);
+      e.M = E; e.bias[0] = bias; e.gamma[0] = bias + 256; e.beta[0] = bias + 512; e.eps = 1e-5f; e.C = C; e.ldc = 256;
+      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>>), dim3(496, 1), dim3(512), 0, 0, g, ap, e); }, 20);
+      report("cs edge_mlp2 M63488 K256 N256 LN", ms, 2.0 * E * 256 * 256);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiNull>), dim3(496, 1), dim3(512), 0, 0, g, ap, en); }, 20);
+      report("cs           M63488 K256 N256 no epilogue", ms, 2.0 * E * 256 * 256);
+      GemmCore g2 = core(M, 256, 1, 256);
+      e.M = M;
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>>), dim3(232, 1), dim3(512), 0, 0, g2, ap, e); }, 20);
+      report("cs node_mlp2 M29696 K256 N256 LN", ms, 2.0 * M * 256 * 256);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiNull>), dim3(232, 1), dim3(512), 0, 0, g2, ap, en); }, 20);
+      report("cs           M29696 K256 N256 no epilogue", ms, 2.0 * M * 256 * 256);
+    }
   }
   return 0;
 }

@@ -1,0 +1,44 @@
+// Sustained v_mfma_f32_32x32x2_f32 rate from registers only (no memory traffic): the ceiling
+// that the GEMM main loops are measured against.  Usage: ./mfma_peak
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_mfma(float* out, int iters) {
+  f32x16 acc[4];
+  for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 16; ++r) s += acc[t][r];
+  if (s == 123.456f) out[0] = s;
+}
+
+int main() {
+  float* d;
+  hipMalloc(&d, 4);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 2000;
+  for (int wpb = 1; wpb <= 4; wpb *= 2) {       // workgroups per CU (4 waves each)
+    const int blocks = 256 * wpb;
+    hipLaunchKernelGGL(k_mfma, dim3(blocks), dim3(256), 0, 0, d, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_mfma, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)blocks * 4 * iters * 32 * 4096.0;
+    printf("waves/SIMD %d: %.3f ms  %.1f TFLOP/s\n", wpb, ms, flop / (ms * 1e-3) / 1e12);
+  }
+  return 0;
+}
