@@ -114,35 +114,66 @@ struct EpiGate {
       }
     }
   }
+  // Column-split form.  Everything that does not depend on the accumulators is loaded up
+  // front in one batch (residual rows, molecule ids, and - when all molecules share one
+  // timestep, mod_stride == 0 - the gate / scale / shift vectors): a load left behind a
+  // store through a possibly aliasing pointer (X may BE resid) cannot be hoisted by the
+  // compiler and would cost one memory latency per row.
   template <class MB>
   __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
     const int c0 = lane & 31;
     const int cb = half * 128 + c0;
-    float bv[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) bv[ct] = bias[cb + ct * 32];
-    float mean[16], q2[16];
+    const bool shared_mod = mod_stride == 0;
+    float rs[4][16];
+    int mol[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + G_ROW(r, lane);
       const int rr = row < M ? row : M - 1;
-      const float* g = mod + (size_t)atom_mol[rr] * mod_stride + gate_off;
-      float s = 0.f;
+      mol[r] = shared_mod ? 0 : atom_mol[rr];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const int col = cb + ct * 32;
-        const float pr = acc[ct][r] + bv[ct];
-        if (proj_out != nullptr && row < M) proj_out[(size_t)row * 256 + col] = pr;
-        acc[ct][r] = resid[(size_t)rr * 256 + col] + g[col] * pr;
-        s += acc[ct][r];
-        if (row < M) X[(size_t)row * 256 + col] = acc[ct][r];
+      for (int ct = 0; ct < 4; ++ct) rs[ct][r] = resid[(size_t)rr * 256 + cb + ct * 32];
+    }
+    float bv[4], g0[4], sc0[4], sh0[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      bv[ct] = bias[cb + ct * 32];
+      g0[ct] = mod[gate_off + cb + ct * 32];
+      sc0[ct] = LNMOD ? mod2[scale_off + cb + ct * 32] : 0.f;
+      sh0[ct] = LNMOD ? mod2[shift_off + cb + ct * 32] : 0.f;
+    }
+    float mean[16], q2[16];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {          // rows in two batches of 8: bounded registers for per-molecule gates
+      float gt[4][8];
+      if (!shared_mod) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            gt[ct][i] = mod[(size_t)mol[hb * 8 + i] * mod_stride + gate_off + cb + ct * 32];
       }
-      if (LNMOD) {
-        mean[r] = half_wave_sum(s) * (1.0f / 128.0f);
-        float q = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { const float d = acc[ct][r] - mean[r]; q += d * d; }
-        q2[r] = half_wave_sum(q);
+      for (int i = 0; i < 8; ++i) {
+        const int r = hb * 8 + i;
+        const int row = row0 + G_ROW(r, lane);
+        float s = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int col = cb + ct * 32;
+          const float pr = acc[ct][r] + bv[ct];
+          if (proj_out != nullptr && row < M) proj_out[(size_t)row * 256 + col] = pr;
+          acc[ct][r] = rs[ct][r] + (shared_mod ? g0[ct] : gt[ct][i]) * pr;
+          s += acc[ct][r];
+          if (row < M) X[(size_t)row * 256 + col] = acc[ct][r];
+        }
+        if (LNMOD) {
+          mean[r] = half_wave_sum(s) * (1.0f / 128.0f);
+          float q = 0.f;
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) { const float d = acc[ct][r] - mean[r]; q += d * d; }
+          q2[r] = half_wave_sum(q);
+        }
       }
     }
     if (LNMOD) {
@@ -151,17 +182,32 @@ struct EpiGate {
       float pmean[16], pq2[16];
       mb.get_partner(0, pmean); mb.get_partner(1, pq2);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + G_ROW(r, lane);
-        const float dm = mean[r] - pmean[r];
-        const float mu = 0.5f * (mean[r] + pmean[r]);
-        const float rstd = 1.0f / sqrtf((q2[r] + pq2[r] + 64.0f * dm * dm) * (1.0f / 256.0f) + 1e-6f);
-        if (row < M) {
-          const float* m2 = mod2 + (size_t)atom_mol[row] * mod_stride;
+      for (int hb = 0; hb < 2; ++hb) {
+        float sct[4][8], sht[4][8];
+        if (!shared_mod) {
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) {
-            const int col = cb + ct * 32;
-            XN[(size_t)row * 256 + col] = ((acc[ct][r] - mu) * rstd) * (1.0f + m2[scale_off + col]) + m2[shift_off + col];
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              const float* m2 = mod2 + (size_t)mol[hb * 8 + i] * mod_stride + cb + ct * 32;
+              sct[ct][i] = m2[scale_off]; sht[ct][i] = m2[shift_off];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = hb * 8 + i;
+          const int row = row0 + G_ROW(r, lane);
+          const float dm = mean[r] - pmean[r];
+          const float mu = 0.5f * (mean[r] + pmean[r]);
+          const float rstd = 1.0f / sqrtf((q2[r] + pq2[r] + 64.0f * dm * dm) * (1.0f / 256.0f) + 1e-6f);
+          if (row < M) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              const int col = cb + ct * 32;
+              const float sc = shared_mod ? sc0[ct] : sct[ct][i];
+              const float sh = shared_mod ? sh0[ct] : sht[ct][i];
+              XN[(size_t)row * 256 + col] = ((acc[ct][r] - mu) * rstd) * (1.0f + sc) + sh;
+            }
           }
         }
       }
@@ -201,24 +247,37 @@ struct EpiEdgePre {
       }
     }
   }
+  // Column-split form: all row indices, then all gathered P values, are loaded in two
+  // batches before the first store (see EpiGate::cs for why).
   template <class MB>
   __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
     const int cb = half * 128 + (lane & 31);
+    int is[16], id[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      const int rr = row < M ? row : M - 1;
+      is[r] = src[rr]; id[r] = dst[rr];
+    }
     float bv[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) bv[ct] = b1[cb + ct * 32];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      const float* pa = P + (size_t)is[r] * 512 + cb;
+      const float* pb = P + (size_t)id[r] * 512 + 256 + cb;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[ct][r] = (pa[ct * 32] + pb[ct * 32]) + (acc[ct][r] + bv[ct]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
       const int row = row0 + G_ROW(r, lane);
       if (row < M) {
-        const float* pa = P + (size_t)src[row] * 512;
-        const float* pb = P + (size_t)dst[row] * 512 + 256;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
           const int col = cb + ct * 32;
-          const float v = (pa[col] + pb[col]) + (acc[ct][r] + bv[ct]);
-          A1[(size_t)row * 256 + col] = silu(v);
-          if (pre_out != nullptr) pre_out[(size_t)row * 256 + col] = v;
+          A1[(size_t)row * 256 + col] = silu(acc[ct][r]);
+          if (pre_out != nullptr) pre_out[(size_t)row * 256 + col] = acc[ct][r];
         }
       }
     }
@@ -242,6 +301,13 @@ struct EpiCoord {
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { bv[ct] = b1[ct * 32 + c0]; wv[ct] = w2[ct * 32 + c0]; }
     const float bias2 = b2[0];
+    float rl[16];   // rel of this lane's coordinate, loaded ahead of the first store
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      const int rr = row < M ? row : M - 1;
+      rl[r] = c0 < 3 ? rel[(size_t)rr * 4 + c0] : 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + G_ROW(r, lane);
@@ -253,7 +319,7 @@ struct EpiCoord {
         if (hid_out != nullptr && row < M) hid_out[(size_t)row * 128 + ct * 32 + c0] = u;
       }
       const float cw = tanhf(half_wave_sum(s) + bias2);
-      if (row < M && c0 < 3) wrel[(size_t)row * 4 + c0] = rel[(size_t)row * 4 + c0] * cw;
+      if (row < M && c0 < 3) wrel[(size_t)row * 4 + c0] = rl[r] * cw;
       if (cw_out != nullptr && row < M && c0 == 3) cw_out[row] = cw;
     }
   }

@@ -295,13 +295,30 @@ struct EpiLN {
       }
     }
   }
+  // Loads that do not depend on the accumulators (the residual rows) are issued first, in one
+  // batch: the compiler may not move a load above an earlier store through a possibly aliasing
+  // pointer (C may BE resid), so loads left inside the row loop would each wait out a full
+  // memory latency behind the previous row's stores.
   template <class MB>
   __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
     const int c0 = lane & 31;
     const int cb = by * 256 + half * 128;
+    float rs[RESID ? 4 : 1][16];
+    if (RESID) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + G_ROW(r, lane);
+        const int rr = row < M ? row : M - 1;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) rs[ct][r] = resid[(size_t)rr * ldr + cb + ct * 32 + c0];
+      }
+    }
     float bv[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) bv[ct] = bias[by][half * 128 + ct * 32 + c0];
+    float gv[4], be[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { gv[ct] = gamma[by][half * 128 + ct * 32 + c0]; be[ct] = beta[by][half * 128 + ct * 32 + c0]; }
     float mean[16], m2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -324,9 +341,6 @@ struct EpiLN {
     __syncthreads();
     float pmean[16], pm2[16];
     mb.get_partner(0, pmean); mb.get_partner(1, pm2);
-    float gv[4], be[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) { gv[ct] = gamma[by][half * 128 + ct * 32 + c0]; be[ct] = beta[by][half * 128 + ct * 32 + c0]; }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + G_ROW(r, lane);
@@ -339,7 +353,7 @@ struct EpiLN {
         for (int ct = 0; ct < 4; ++ct) {
           const size_t o = (size_t)row * ldc + cb + ct * 32 + c0;
           float y = apply_act<POST_ACT>((acc[ct][r] - mu) * rstd * gv[ct] + be[ct]);
-          if (RESID) y += resid[(size_t)row * ldr + cb + ct * 32 + c0];
+          if (RESID) y += rs[ct][r];
           C[o] = y;
         }
       }

@@ -171,5 +171,36 @@ int main() {
       report("cs           M29696 K256 N256 no epilogue", ms, 2.0 * M * 256 * 256);
     }
   }
+  printf("--- cold operands: rotating over 6 buffer sets (A, resid, C each 30 MB; W 6 copies)\n");
+  {
+    float* big;
+    CK(hipMalloc(&big, (size_t)6 * 3 * M * 256 * 4));
+    CK(hipMemset(big, 0, (size_t)6 * 3 * M * 256 * 4));
+    int it = 0;
+    GemmCore g2 = core(M, 256, 1, 256);
+    APtrPlain ap{A, 256};
+    EpiLN<ACT_NONE, ACT_NONE, true> e; memset(&e, 0, sizeof e);
+    e.M = M; e.bias[0] = bias; e.gamma[0] = bias + 256; e.beta[0] = bias + 512; e.eps = 1e-5f; e.ldc = 256; e.ldr = 256;
+    auto run = [&](bool rotate) {
+      const int k = rotate ? (it++ % 6) : 0;
+      float* base = big + (size_t)k * 3 * M * 256;
+      ap.A = base; e.resid = base + (size_t)M * 256; e.C = base + (size_t)2 * M * 256;
+      g2.W[0] = W + (size_t)k * 65536;
+      hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, true>>), dim3(232, 1), dim3(512), 0, 0, g2, ap, e);
+    };
+    float ms = time_it([&] { run(false); }, 24);
+    report("cs node_mlp2 +resid, same buffers", ms, 2.0 * M * 256 * 256);
+    ms = time_it([&] { run(true); }, 24);
+    report("cs node_mlp2 +resid, rotating buffers", ms, 2.0 * M * 256 * 256);
+    auto run_inplace = [&](bool rotate) {
+      const int k = rotate ? (it++ % 6) : 0;
+      float* base = big + (size_t)k * 3 * M * 256;
+      ap.A = base; e.resid = base + (size_t)M * 256; e.C = base + (size_t)M * 256;
+      g2.W[0] = W + (size_t)k * 65536;
+      hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, true>>), dim3(232, 1), dim3(512), 0, 0, g2, ap, e);
+    };
+    ms = time_it([&] { run_inplace(true); }, 24);
+    report("cs node_mlp2 +resid in place, rotating", ms, 2.0 * M * 256 * 256);
+  }
   return 0;
 }
