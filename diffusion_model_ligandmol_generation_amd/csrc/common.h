@@ -19,25 +19,38 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     if (hipGetLastError() != hipSuccess) return LIGDIFF_ERR_LAUNCH; \
   } while (0)
 
-// erf with absolute error <= 1.5e-7 (Abramowitz & Stegun 7.1.26):
-//   1 - (a1 t + ... + a5 t^5) exp(-x^2),  t = 1 / (1 + p |x|).
-// One reciprocal, one exponential and eight FMAs - about a third of the instructions of the
-// library erff - which matters because GELU runs inside the GEMM epilogues.  The error it
-// adds to GELU(v) = v (1 + erf(v / sqrt 2)) / 2 is below 1e-7 |v|.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  float p = 1.061405429f;
-  p = p * t - 1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t - 0.284496736f;
-  p = p * t + 0.254829592f;
-  const float r = 1.0f - (p * t) * __expf(-ax * ax);
-  return copysignf(r, x);
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// erf with absolute error <= 3e-7 (Abramowitz & Stegun 7.1.28):
+//   1 - (1 + a1 t + ... + a6 t^6)^-16,  t = |x|.
+// Six FMAs, four squarings and ONE reciprocal, no exponential: the transcendental unit runs at
+// a quarter of the FMA rate, and GELU sits inside GEMM epilogues that are VALU-bound.  The
+// two-wide form keeps the polynomial on packed fp32 instructions (v_pk_fma_f32: two lanes of
+// work per issue).  For |x| > ~9 the power overflows to +inf and the reciprocal gives 0.
+__device__ __forceinline__ f32x2 erf_fast2(f32x2 x) {
+  const f32x2 t = __builtin_elementwise_abs(x);
+  f32x2 p = t * 0.0000430638f + 0.0002765672f;
+  p = p * t + 0.0001520143f;
+  p = p * t + 0.0092705272f;
+  p = p * t + 0.0422820123f;
+  p = p * t + 0.0705230784f;
+  p = p * t + 1.0f;
+  p = p * p; p = p * p; p = p * p; p = p * p;
+  f32x2 r;
+  r[0] = 1.0f - __builtin_amdgcn_rcpf(p[0]);
+  r[1] = 1.0f - __builtin_amdgcn_rcpf(p[1]);
+  r[0] = copysignf(r[0], x[0]);
+  r[1] = copysignf(r[1], x[1]);
+  return r;
+}
+// nn.GELU() default (erf form), model1.py:602 / :615 / :638
+__device__ __forceinline__ f32x2 gelu_exact2(f32x2 v) {
+  const f32x2 hv = v * 0.5f;
+  return hv * erf_fast2(v * 0.70710678118654752440f) + hv;
 }
 __device__ __forceinline__ float gelu_exact(float v) {
-  // nn.GELU() default (erf form), model1.py:602 / :615 / :638
-  return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f));
+  const f32x2 g = gelu_exact2(f32x2{v, v});
+  return g[0];
 }
 // SiLU through the hardware exp2 / reciprocal (relative error ~1e-6 for |v| < 16): it sits
 // in GEMM epilogues, where the IEEE division and the library expf cost ~4x the instructions.

@@ -386,7 +386,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       }
     }
     PB("e3_%d.aggregate", l);
-    hipLaunchKernelGGL(k_aggregate, dim3(ceil_div(N, 4)), dim3(256), 0, s, F(L.msg[l]), F(L.wrel[l]), g->dst_ptr,
+    hipLaunchKernelGGL(k_aggregate, dim3(ceil_div(N, 8)), dim3(256), 0, s, F(L.msg[l]), F(L.wrel[l]), g->dst_ptr,
                        g->src_ptr, g->src_slot, pos, F(L.pos_upd), F(L.pos_cur), F(L.agg[l]), (float*)nullptr, N,
                        l == 0 ? 1 : 0);
     PE();

@@ -227,8 +227,10 @@ struct EpiBiasAct {
       }
     }
   }
-  template <class MB>
-  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
+  // Column-split form.  The optional outputs are a template switch so that the row loop has
+  // no per-element branch, and GELU runs two columns at a time on packed fp32 instructions.
+  template <bool PRE, class MB>
+  __device__ __forceinline__ void cs_body(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
     const int c0 = lane & 31;
     const float* b = bias[by];
     float bv[4];
@@ -238,17 +240,30 @@ struct EpiBiasAct {
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + G_ROW(r, lane);
       if (row < M) {
+        const size_t o0 = (size_t)row * ldc + (size_t)by * col_block + half * 128 + c0;
+        float u[4], v[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) u[ct] = acc[ct][r] * alpha + bv[ct];
+        if (ACT == ACT_GELU) {
+          const f32x2 g0 = gelu_exact2(f32x2{u[0], u[1]}), g1 = gelu_exact2(f32x2{u[2], u[3]});
+          v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) v[ct] = apply_act<ACT>(u[ct]);
+        }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-          const float u = acc[ct][r] * alpha + bv[ct];
-          const float v = apply_act<ACT>(u);
-          const size_t o = (size_t)row * ldc + (size_t)by * col_block + half * 128 + ct * 32 + c0;
-          C[o] = v;
-          if (pre_out != nullptr) pre_out[o] = u;
-          if (DUAL_SILU) C2[o] = silu(v);
+          C[o0 + ct * 32] = v[ct];
+          if (PRE) pre_out[o0 + ct * 32] = u[ct];
+          if (DUAL_SILU) C2[o0 + ct * 32] = silu(v[ct]);
         }
       }
     }
+  }
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
+    if (pre_out != nullptr) cs_body<true>(acc, row0, by, half, lane, mb);
+    else cs_body<false>(acc, row0, by, half, lane, mb);
   }
 };
 

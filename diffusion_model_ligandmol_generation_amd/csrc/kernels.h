@@ -102,39 +102,55 @@ __global__ __launch_bounds__(256) void k_edge_geom(
 //   agg[i]      = sum_{e in in(i)} msg[e]
 //   dpos[i]     = sum_{e in in(i)} wrel[e] - sum_{e in out(i)} wrel[e]
 //   pos_upd[i] += 0.1 dpos[i];  pos_cur[i] = pos[i] + pos_upd[i]
+// Two atoms per wave (one per 32-lane half, 32 B of every row per lane) and all four CSR
+// bounds loaded up front: an atom has ~2 incoming edges, so the kernel is a chain of three
+// dependent memory latencies and its rate is set by how many of them are in flight.
 __global__ __launch_bounds__(256) void k_aggregate(
     const float* __restrict__ msg, const float* __restrict__ wrel,
     const int32_t* __restrict__ dst_ptr, const int32_t* __restrict__ src_ptr,
     const int32_t* __restrict__ src_slot, const float* __restrict__ pos,
     float* __restrict__ pos_upd, float* __restrict__ pos_cur, float* __restrict__ agg,
     float* __restrict__ dpos_out, int N, int first_layer) {
-  const int lane = threadIdx.x & 63;
-  const int node = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 31;
+  const int node = blockIdx.x * 8 + (threadIdx.x >> 5);
   if (node >= N) return;
   const int e0 = dst_ptr[node], e1 = dst_ptr[node + 1];
-  f32x4 a0 = {0.f, 0.f, 0.f, 0.f};
-  int e = e0;
-  for (; e + 4 <= e1; e += 4) {  // 4 rows in flight per wave
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(msg + (size_t)(e + 0) * 256 + lane * 4);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(msg + (size_t)(e + 1) * 256 + lane * 4);
-    const f32x4 v2 = *reinterpret_cast<const f32x4*>(msg + (size_t)(e + 2) * 256 + lane * 4);
-    const f32x4 v3 = *reinterpret_cast<const f32x4*>(msg + (size_t)(e + 3) * 256 + lane * 4);
-    a0 = (((a0 + v0) + v1) + v2) + v3;
-  }
-  for (; e < e1; ++e) a0 += *reinterpret_cast<const f32x4*>(msg + (size_t)e * 256 + lane * 4);
-  *reinterpret_cast<f32x4*>(agg + (size_t)node * 256 + lane * 4) = a0;
-
-  const int c = lane & 3;
-  float d = 0.f;
-  for (int k = e0 + (lane >> 2); k < e1; k += 16) d += wrel[(size_t)k * 4 + c];
   const int s0 = src_ptr[node], s1 = src_ptr[node + 1];
-  for (int k = s0 + (lane >> 2); k < s1; k += 16) d -= wrel[(size_t)src_slot[k] * 4 + c];
+  const int c = l & 3, g = l >> 2;
+  // coordinate part first: its loads (wrel of incoming edges, slots of outgoing edges) go
+  // out together with the first message rows
+  float d = 0.f;
+  int slot[2];
+  const int k0 = s0 + g, k1 = s0 + g + 8;
+  slot[0] = k0 < s1 ? src_slot[k0] : -1;
+  slot[1] = k1 < s1 ? src_slot[k1] : -1;
+  for (int k = e0 + g; k < e1; k += 8) d += wrel[(size_t)k * 4 + c];
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  const float* mrow = msg + l * 4;
+  int e = e0;
+  for (; e + 2 <= e1; e += 2) {  // 2 rows (4 loads of 16 B) in flight per half-wave
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(mrow + (size_t)(e + 0) * 256);
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(mrow + (size_t)(e + 0) * 256 + 128);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(mrow + (size_t)(e + 1) * 256);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(mrow + (size_t)(e + 1) * 256 + 128);
+    a0 = (a0 + v0) + v1;
+    a1 = (a1 + w0) + w1;
+  }
+  if (e < e1) {
+    a0 += *reinterpret_cast<const f32x4*>(mrow + (size_t)e * 256);
+    a1 += *reinterpret_cast<const f32x4*>(mrow + (size_t)e * 256 + 128);
+  }
+  *reinterpret_cast<f32x4*>(agg + (size_t)node * 256 + l * 4) = a0;
+  *reinterpret_cast<f32x4*>(agg + (size_t)node * 256 + 128 + l * 4) = a1;
+
+  if (slot[0] >= 0) d -= wrel[(size_t)slot[0] * 4 + c];
+  if (slot[1] >= 0) d -= wrel[(size_t)slot[1] * 4 + c];
+  for (int k = s0 + g + 16; k < s1; k += 8) d -= wrel[(size_t)src_slot[k] * 4 + c];
   d += __shfl_xor(d, 4);
   d += __shfl_xor(d, 8);
   d += __shfl_xor(d, 16);
-  d += __shfl_xor(d, 32);
-  if (lane < 3) {
-    const size_t o = (size_t)node * 3 + lane;
+  if (l < 3) {
+    const size_t o = (size_t)node * 3 + l;
     if (dpos_out != nullptr) dpos_out[o] = d;
     const float pu = (first_layer ? 0.f : pos_upd[o]) + d * 0.1f;
     pos_upd[o] = pu;
