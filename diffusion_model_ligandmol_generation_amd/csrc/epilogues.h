@@ -119,39 +119,34 @@ struct EpiGate {
   // timestep, mod_stride == 0 - the gate / scale / shift vectors): a load left behind a
   // store through a possibly aliasing pointer (X may BE resid) cannot be hoisted by the
   // compiler and would cost one memory latency per row.
-  template <class MB>
-  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
+  template <bool SAVE, class MB>
+  __device__ __forceinline__ void cs_body(f32x16 (&acc_t)[4], int row0, int by, int half, int lane, const MB& mb) const {
+    float acc[4][16];   // plain scalars: element updates on the 16-register MFMA tuples would copy whole tuples
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = acc_t[ct][r];
     const int c0 = lane & 31;
     const int cb = half * 128 + c0;
     const bool shared_mod = mod_stride == 0;
-    float rs[4][16];
-    int mol[16];
+    float bv[4], g0[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + G_ROW(r, lane);
-      const int rr = row < M ? row : M - 1;
-      mol[r] = shared_mod ? 0 : atom_mol[rr];
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) rs[ct][r] = resid[(size_t)rr * 256 + cb + ct * 32];
-    }
-    float bv[4], g0[4], sc0[4], sh0[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      bv[ct] = bias[cb + ct * 32];
-      g0[ct] = mod[gate_off + cb + ct * 32];
-      sc0[ct] = LNMOD ? mod2[scale_off + cb + ct * 32] : 0.f;
-      sh0[ct] = LNMOD ? mod2[shift_off + cb + ct * 32] : 0.f;
-    }
+    for (int ct = 0; ct < 4; ++ct) { bv[ct] = bias[cb + ct * 32]; g0[ct] = mod[gate_off + cb + ct * 32]; }
+    // phase A (no stores unless SAVE): x = resid + gate * (acc + bias) in place, half-row statistics
     float mean[16], q2[16];
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {          // rows in two batches of 8: bounded registers for per-molecule gates
-      float gt[4][8];
-      if (!shared_mod) {
+    for (int hb = 0; hb < 2; ++hb) {
+      float rs[4][8], gt[4][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i) {
+        const int row = row0 + G_ROW(hb * 8 + i, lane);
+        const int rr = row < M ? row : M - 1;
+        const size_t mo = shared_mod ? 0 : (size_t)atom_mol[rr] * mod_stride;
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct)
-            gt[ct][i] = mod[(size_t)mol[hb * 8 + i] * mod_stride + gate_off + cb + ct * 32];
+        for (int ct = 0; ct < 4; ++ct) {
+          rs[ct][i] = resid[(size_t)rr * 256 + cb + ct * 32];
+          gt[ct][i] = shared_mod ? g0[ct] : mod[mo + gate_off + cb + ct * 32];
+        }
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -160,12 +155,10 @@ struct EpiGate {
         float s = 0.f;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-          const int col = cb + ct * 32;
           const float pr = acc[ct][r] + bv[ct];
-          if (proj_out != nullptr && row < M) proj_out[(size_t)row * 256 + col] = pr;
-          acc[ct][r] = rs[ct][r] + (shared_mod ? g0[ct] : gt[ct][i]) * pr;
+          if (SAVE && row < M) proj_out[(size_t)row * 256 + cb + ct * 32] = pr;
+          acc[ct][r] = rs[ct][i] + gt[ct][i] * pr;
           s += acc[ct][r];
-          if (row < M) X[(size_t)row * 256 + col] = acc[ct][r];
         }
         if (LNMOD) {
           mean[r] = half_wave_sum(s) * (1.0f / 128.0f);
@@ -174,6 +167,7 @@ struct EpiGate {
           for (int ct = 0; ct < 4; ++ct) { const float d = acc[ct][r] - mean[r]; q += d * d; }
           q2[r] = half_wave_sum(q);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (LNMOD) {
@@ -182,36 +176,57 @@ struct EpiGate {
       float pmean[16], pq2[16];
       mb.get_partner(0, pmean); mb.get_partner(1, pq2);
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-        float sct[4][8], sht[4][8];
-        if (!shared_mod) {
+      for (int r = 0; r < 16; ++r) {   // mean[] <- row mean, q2[] <- 1/std
+        const float dm = mean[r] - pmean[r];
+        const float var = (q2[r] + pq2[r] + 64.0f * dm * dm) * (1.0f / 256.0f);
+        mean[r] = 0.5f * (mean[r] + pmean[r]);
+        q2[r] = 1.0f / sqrtf(var + 1e-6f);
+      }
+    }
+    // phase B: stores; per-molecule scale / shift rows are fetched eight rows at a time
+    float sc0[4], sh0[4];
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+    for (int ct = 0; ct < 4; ++ct) {
+      sc0[ct] = LNMOD ? mod2[scale_off + cb + ct * 32] : 0.f;
+      sh0[ct] = LNMOD ? mod2[shift_off + cb + ct * 32] : 0.f;
+    }
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-              const float* m2 = mod2 + (size_t)mol[hb * 8 + i] * mod_stride + cb + ct * 32;
-              sct[ct][i] = m2[scale_off]; sht[ct][i] = m2[shift_off];
-            }
-        }
+    for (int hb = 0; hb < 2; ++hb) {
+      float sct[4][8], sht[4][8];
+      if (LNMOD && !shared_mod) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int r = hb * 8 + i;
-          const int row = row0 + G_ROW(r, lane);
-          const float dm = mean[r] - pmean[r];
-          const float mu = 0.5f * (mean[r] + pmean[r]);
-          const float rstd = 1.0f / sqrtf((q2[r] + pq2[r] + 64.0f * dm * dm) * (1.0f / 256.0f) + 1e-6f);
-          if (row < M) {
+          const int row = row0 + G_ROW(hb * 8 + i, lane);
+          const int rr = row < M ? row : M - 1;
+          const float* m2 = mod2 + (size_t)atom_mol[rr] * mod_stride + cb;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) {
-              const int col = cb + ct * 32;
+          for (int ct = 0; ct < 4; ++ct) { sct[ct][i] = m2[scale_off + ct * 32]; sht[ct][i] = m2[shift_off + ct * 32]; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = hb * 8 + i;
+        const int row = row0 + G_ROW(r, lane);
+        if (row < M) {
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            const int col = cb + ct * 32;
+            X[(size_t)row * 256 + col] = acc[ct][r];
+            if (LNMOD) {
               const float sc = shared_mod ? sc0[ct] : sct[ct][i];
               const float sh = shared_mod ? sh0[ct] : sht[ct][i];
-              XN[(size_t)row * 256 + col] = ((acc[ct][r] - mu) * rstd) * (1.0f + sc) + sh;
+              XN[(size_t)row * 256 + col] = ((acc[ct][r] - mean[r]) * q2[r]) * (1.0f + sc) + sh;
             }
           }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+  }
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
+    if (proj_out != nullptr) cs_body<true>(acc, row0, by, half, lane, mb);
+    else cs_body<false>(acc, row0, by, half, lane, mb);
   }
 };
 
@@ -249,8 +264,8 @@ struct EpiEdgePre {
   }
   // Column-split form: all row indices, then all gathered P values, are loaded in two
   // batches before the first store (see EpiGate::cs for why).
-  template <class MB>
-  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
+  template <bool SAVE, class MB>
+  __device__ __forceinline__ void cs_body(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
     const int cb = half * 128 + (lane & 31);
     int is[16], id[16];
 #pragma unroll
@@ -277,10 +292,15 @@ struct EpiEdgePre {
         for (int ct = 0; ct < 4; ++ct) {
           const int col = cb + ct * 32;
           A1[(size_t)row * 256 + col] = silu(acc[ct][r]);
-          if (pre_out != nullptr) pre_out[(size_t)row * 256 + col] = acc[ct][r];
+          if (SAVE) pre_out[(size_t)row * 256 + col] = acc[ct][r];
         }
       }
     }
+  }
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
+    if (pre_out != nullptr) cs_body<true>(acc, row0, by, half, lane, mb);
+    else cs_body<false>(acc, row0, by, half, lane, mb);
   }
 };
 
@@ -296,6 +316,11 @@ struct EpiCoord {
   float* hid_out;    // nullable: [E,128] pre-activation
   float* cw_out;     // nullable: [E]
   __device__ __forceinline__ void operator()(f32x16 (&acc)[4], int row0, int by, int lane) const {
+    if (hid_out != nullptr) body<true>(acc, row0, lane);
+    else body<false>(acc, row0, lane);
+  }
+  template <bool SAVE>
+  __device__ __forceinline__ void body(f32x16 (&acc)[4], int row0, int lane) const {
     const int c0 = lane & 31;
     float bv[4], wv[4];
 #pragma unroll
@@ -316,11 +341,11 @@ struct EpiCoord {
       for (int ct = 0; ct < 4; ++ct) {
         const float u = acc[ct][r] + bv[ct];
         s += silu(u) * wv[ct];
-        if (hid_out != nullptr && row < M) hid_out[(size_t)row * 128 + ct * 32 + c0] = u;
+        if (SAVE && row < M) hid_out[(size_t)row * 128 + ct * 32 + c0] = u;
       }
       const float cw = tanhf(half_wave_sum(s) + bias2);
       if (row < M && c0 < 3) wrel[(size_t)row * 4 + c0] = rl[r] * cw;
-      if (cw_out != nullptr && row < M && c0 == 3) cw_out[row] = cw;
+      if (SAVE && row < M && c0 == 3) cw_out[row] = cw;
     }
   }
 };

@@ -12,6 +12,7 @@ struct FwdLayout {
   size_t mod[3];                    // adaLN parameters [Bt,1536] per DiT layer
   size_t pemb, pstack, pg;          // PILOT embedding, stacked encoders, pareto hidden
   size_t h0;                        // [N,256] embedding output / residual stream
+  size_t xpad, wpad;                // [N,128] / [256,128] zero-extended atom features and embedding weight
   size_t pos_upd, pos_cur;          // [N,3]
   size_t P[3], rel[3], rbf[3], a1[3], msg[3], wrel[3], agg[3], hid[3], h_e3[3];
   size_t xn1[3], qkv[3], att[3], x1[3], xn2[3], ffh[3], x2[3];

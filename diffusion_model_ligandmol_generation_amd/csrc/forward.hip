@@ -194,6 +194,7 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
   for (int l = 0; l < 3; ++l) L->mod[l] = take(Bt * 1536);
   L->pemb = take((size_t)B * 256); L->pstack = take((size_t)B * 2048); L->pg = take((size_t)B * 256);
   L->h0 = take(N * 256);
+  L->xpad = take(N * 128); L->wpad = take(256 * 128);
   L->pos_upd = take(N * 3); L->pos_cur = take(N * 3);
   // Without SAVE every layer reuses layer 0's scratch and the residual stream is updated
   // in place (each element is read and rewritten by the same thread of the epilogue).
@@ -319,7 +320,22 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     e.temb = F(L.temb); e.temb_stride = tstride; e.pemb = pemb; e.pemb_stride = pstride;
     e.atom_mol = g->atom_mol; e.H = F(L.h0); e.ua_out = S(L.ua);
     PB("embed");
-    launch_gemm<8, W_SCALAR>(gc, al, e, 1, s);
+    if (use_cs()) {
+      hipLaunchKernelGGL(k_pad_embed, dim3(ceil_div(((long)N + 256) * 32, 256)), dim3(256), 0, s, x, w[W_ATOM_W],
+                         F(L.xpad), F(L.wpad), N);
+      // h = GELU(LN(x Wa^T + ba)) + R,  R = GELU(LN(pos Wp^T + bp)) + t_emb (+ prop_emb)
+      float* R = F(L.xn1[0]);   // free until the attention layers
+      hipLaunchKernelGGL(k_pos_embed, dim3(ceil_div(N, 4)), dim3(256), 0, s, pos, w[W_POS_W], w[W_POS_B], w[W_POS_G],
+                         w[W_POS_BE], F(L.temb), tstride, pemb, pstride, g->atom_mol, R, N);
+      GemmCore gp = core_blocks(N, 128, 256, F(L.wpad), 128, 1, 256);
+      EpiLN<ACT_NONE, ACT_GELU, true> el;
+      memset(&el, 0, sizeof el);
+      el.M = N; el.bias[0] = w[W_ATOM_B]; el.gamma[0] = w[W_ATOM_G]; el.beta[0] = w[W_ATOM_BE]; el.eps = 1e-5f;
+      el.C = F(L.h0); el.ldc = 256; el.resid = R; el.ldr = 256; el.pre_out = S(L.ua);
+      launch_gemm_cs(gp, APtrPlain{F(L.xpad), 128}, el, 1, s);
+    } else {
+      launch_gemm<8, W_SCALAR>(gc, al, e, 1, s);
+    }
     PE();
   }
 

@@ -314,10 +314,39 @@ struct EpiLN {
   // batch: the compiler may not move a load above an earlier store through a possibly aliasing
   // pointer (C may BE resid), so loads left inside the row loop would each wait out a full
   // memory latency behind the previous row's stores.
-  template <class MB>
-  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
+  template <bool SAVE, class MB>
+  __device__ __forceinline__ void cs_body(f32x16 (&acc_t)[4], int row0, int by, int half, int lane, const MB& mb) const {
+    float acc[4][16];   // plain scalars: element updates on the 16-register MFMA tuples would copy whole tuples
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = acc_t[ct][r];
     const int c0 = lane & 31;
     const int cb = by * 256 + half * 128;
+    float bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = bias[by][half * 128 + ct * 32 + c0];
+    float mean[16], m2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      float s = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const float u = acc[ct][r] + bv[ct];
+        if (SAVE && row < M) pre_out[(size_t)row * ldc + cb + ct * 32 + c0] = u;
+        acc[ct][r] = apply_act<PRE_ACT>(u);
+        s += acc[ct][r];
+      }
+      mean[r] = half_wave_sum(s) * (1.0f / 128.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) { const float d = acc[ct][r] - mean[r]; q += d * d; }
+      m2[r] = half_wave_sum(q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mb.put(0, mean); mb.put(1, m2);
+    // residual rows: all loads go out before the barrier and before the first store
     float rs[RESID ? 4 : 1][16];
     if (RESID) {
 #pragma unroll
@@ -328,50 +357,39 @@ struct EpiLN {
         for (int ct = 0; ct < 4; ++ct) rs[ct][r] = resid[(size_t)rr * ldr + cb + ct * 32 + c0];
       }
     }
-    float bv[4];
+    __syncthreads();
+    {
+      float pmean[16], pm2[16];
+      mb.get_partner(0, pmean); mb.get_partner(1, pm2);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) bv[ct] = bias[by][half * 128 + ct * 32 + c0];
+      for (int r = 0; r < 16; ++r) {   // mean[] <- row mean, m2[] <- 1/std
+        const float dm = mean[r] - pmean[r];
+        const float var = (m2[r] + pm2[r] + 64.0f * dm * dm) * (1.0f / 256.0f);
+        mean[r] = 0.5f * (mean[r] + pmean[r]);
+        m2[r] = 1.0f / sqrtf(var + eps);
+      }
+    }
     float gv[4], be[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) { gv[ct] = gamma[by][half * 128 + ct * 32 + c0]; be[ct] = beta[by][half * 128 + ct * 32 + c0]; }
-    float mean[16], m2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + G_ROW(r, lane);
-      float s = 0.f;
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const float u = acc[ct][r] + bv[ct];
-        if (pre_out != nullptr && row < M) pre_out[(size_t)row * ldc + cb + ct * 32 + c0] = u;
-        acc[ct][r] = apply_act<PRE_ACT>(u);
-        s += acc[ct][r];
-      }
-      mean[r] = half_wave_sum(s) * (1.0f / 128.0f);
-      float q = 0.f;
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) { const float d = acc[ct][r] - mean[r]; q += d * d; }
-      m2[r] = half_wave_sum(q);
-    }
-    mb.put(0, mean); mb.put(1, m2);
-    __syncthreads();
-    float pmean[16], pm2[16];
-    mb.get_partner(0, pmean); mb.get_partner(1, pm2);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = row0 + G_ROW(r, lane);
-      const float dm = mean[r] - pmean[r];
-      const float mu = 0.5f * (mean[r] + pmean[r]);
-      const float var = (m2[r] + pm2[r] + 64.0f * dm * dm) * (1.0f / 256.0f);
-      const float rstd = 1.0f / sqrtf(var + eps);
       if (row < M) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
           const size_t o = (size_t)row * ldc + cb + ct * 32 + c0;
-          float y = apply_act<POST_ACT>((acc[ct][r] - mu) * rstd * gv[ct] + be[ct]);
+          float y = apply_act<POST_ACT>((acc[ct][r] - mean[r]) * m2[r] * gv[ct] + be[ct]);
           if (RESID) y += rs[ct][r];
           C[o] = y;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // one row at a time: bounds the live temporaries
     }
+  }
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
+    if (pre_out != nullptr) cs_body<true>(acc, row0, by, half, lane, mb);
+    else cs_body<false>(acc, row0, by, half, lane, mb);
   }
 };

@@ -95,6 +95,56 @@ __global__ __launch_bounds__(256) void k_edge_geom(
   }
 }
 
+// Zero-extends the 119-wide atom features and the atom-embedding weight rows to 128 floats
+// (512-B rows), the form the LDS-DMA GEMM needs (16-B aligned rows, K a multiple of 16).
+// Rows [0,N) come from x, rows [N, N+256) from W; one thread writes 16 B.
+__global__ __launch_bounds__(256) void k_pad_embed(const float* __restrict__ x, const float* __restrict__ W,
+                                                   float* __restrict__ xpad, float* __restrict__ wpad, int N) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = i >> 5;
+  const int q = (int)(i & 31) * 4;
+  if (row >= (long)N + 256) return;
+  const float* src = row < N ? x + row * LD_A : W + (row - N) * LD_A;
+  float* dst = row < N ? xpad + row * 128 : wpad + (row - N) * 128;
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (q + e) < LD_A ? src[q + e] : 0.f;
+  *reinterpret_cast<f32x4*>(dst + q) = v;
+}
+
+// Position / time part of the input embedding, model1.py:710-718 (one wave per atom):
+//   R = GELU(LN(pos Wp^T + bp)) + t_emb[mol] (+ prop_emb[mol])
+// The atom-feature GEMM adds its own LayerNorm + GELU branch on top of R in its epilogue.
+__global__ __launch_bounds__(256) void k_pos_embed(const float* __restrict__ pos, const float* __restrict__ Wp,
+                                                   const float* __restrict__ bp, const float* __restrict__ gp,
+                                                   const float* __restrict__ bep, const float* __restrict__ temb,
+                                                   int temb_stride, const float* __restrict__ pemb, int pemb_stride,
+                                                   const int32_t* __restrict__ atom_mol, float* __restrict__ R, int N) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float p0 = pos[(size_t)row * 3 + 0], p1 = pos[(size_t)row * 3 + 1], p2 = pos[(size_t)row * 3 + 2];
+  const int mol = atom_mol[row];
+  f32x4 u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int col = lane * 4 + i;
+    u[i] = (p0 * Wp[col * 3 + 0] + p1 * Wp[col * 3 + 1]) + p2 * Wp[col * 3 + 2] + bp[col];
+  }
+  const float mean = wave_sum((u[0] + u[1]) + (u[2] + u[3])) * (1.0f / 256.0f);
+  const f32x4 d = u - mean;
+  const float var = wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gp + lane * 4);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(bep + lane * 4);
+  f32x4 t = *reinterpret_cast<const f32x4*>(temb + (size_t)mol * temb_stride + lane * 4);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = gelu_exact(d[i] * rstd * g[i] + b[i]) + t[i];
+  if (pemb != nullptr) o += *reinterpret_cast<const f32x4*>(pemb + (size_t)mol * pemb_stride + lane * 4);
+  *reinterpret_cast<f32x4*>(R + (size_t)row * 256 + lane * 4) = o;
+}
+
 // Message aggregation + coordinate scatter, model1.py:100 / :110-112 / :724-725.
 // One wave per destination atom.  The atom's incoming messages are CONTIGUOUS rows of
 // msg (CSR order), so the sum streams 1-KiB rows, 16 B per lane, in the fixed edge order
