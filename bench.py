@@ -27,6 +27,11 @@ ATOMS = 29
 T_STEPS = 1000
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0            # MI355X HBM3E peak
+# HBM-side bytes per launch at this workload from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE,
+# the gfx950 correction for wide reads); the counters cannot be read from inside this process, so
+# these are the figures of the committed profile (profiles/r1_b_pmc_summary.csv), not live ones.
+FFN_UP_TRAFFIC_BYTES = 2 * 43616.9e3 * 1.024 + 118784.0e3 * 1.024
+AGGREGATE_TRAFFIC_BYTES = 2 * 35435.5e3 * 1.024 + 30404.5e3 * 1.024
 
 
 def build_model(device):
@@ -121,16 +126,16 @@ def main():
         ms_ffn = eng.time_launch("dit1.ffn_up", graph, x, pos, t_index, reps=10)
         flops_ffn = 2.0 * N * 256 * 1024
         ach = flops_ffn / (ms_ffn * 1e-3) / 1e12
-        roofline = {"kernel": "gemm_rows_kernel<8,...,EpiBiasAct<8,GELU>> (dit*.ffn_up, M=29696 K=256 N=1024)",
+        roofline = {"kernel": "gemm_cs_kernel<APtrPlain, EpiBiasAct<8,GELU>> (dit*.ffn_up, M=29696 K=256 N=1024)",
                     "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms_ffn}
+                    "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": FFN_UP_TRAFFIC_BYTES, "avg_launch_ms": ms_ffn}
         # ---- the aggregation kernel against the HBM roofline (north-star target kernel)
         E = graph.n_edges
         ms_agg = eng.time_launch("e3_1.aggregate", graph, x, pos, t_index, reps=10)
         bytes_agg = E * 1024.0 + N * 1024.0 + E * 16.0 * 2 + N * 36.0          # msg rows in, agg rows out, wrel, pos
         agg_gbs = bytes_agg / (ms_agg * 1e-3) / 1e9
         roofline_agg = {"kernel": "k_aggregate (e3_*.aggregate)", "bound": "hbm", "achieved": agg_gbs,
-                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": agg_gbs / PEAK_HBM_GBS, "traffic": None,
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": agg_gbs / PEAK_HBM_GBS, "traffic": AGGREGATE_TRAFFIC_BYTES,
                         "avg_launch_ms": ms_agg}
         out = {
             "metric": "sampled molecules/sec (1000-step DDPM)", "value": value, "unit": "molecules/s",

@@ -76,6 +76,18 @@ extern "C" int ligdiff_forward_timed(const float* const* weights, const ligdiff_
   FwdProbe p;
   p.label = label; p.hits = 0;
   if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return LIGDIFF_ERR_LAUNCH;
+  // cost of an empty event pair on this stream (the events bracket exactly one launch; what is
+  // left after subtracting this is the kernel's own duration, as a kernel trace reports it)
+  float empty_ms = 1e30f;
+  for (int i = 0; i < 5; ++i) {
+    float ms = 0.f;
+    if (hipEventRecord(p.e0, s) != hipSuccess || hipEventRecord(p.e1, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess || hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) {
+      rc = LIGDIFF_ERR_LAUNCH;
+      break;
+    }
+    empty_ms = ms < empty_ms ? ms : empty_ms;
+  }
   double total = 0.0;
   for (int i = 0; i < reps && rc == 0; ++i) {
     p.hits = 0;
@@ -85,7 +97,7 @@ extern "C" int ligdiff_forward_timed(const float* const* weights, const ligdiff_
     if (rc == 0 && p.hits != 1) rc = LIGDIFF_ERR_ARG;  // unknown label
     float ms = 0.f;
     if (rc == 0 && hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
-    total += ms;
+    total += ms > empty_ms ? ms - empty_ms : 0.f;
   }
   (void)hipEventDestroy(p.e0);
   (void)hipEventDestroy(p.e1);

@@ -187,7 +187,8 @@ int ligdiff_loss_finish(const ligdiff_loss_args* args, const float* sums8, float
 
 /* Measurement hook (no counterpart in the reference): runs `reps` forwards and returns in
  * *mean_ms_host (host pointer) the mean duration, from HIP events recorded on `stream`, of
- * the one launch labelled `label` (e.g. "dit1.ffn_up", "e3_1.aggregate", "dit0.qkv").
+ * the one launch labelled `label` (e.g. "dit1.ffn_up", "e3_1.aggregate", "dit0.qkv"),
+ * net of the cost of an empty event pair measured on the same stream.
  * Creates two events and synchronises the stream; not for the serving path. */
 int ligdiff_forward_timed(const float* const* weights, const ligdiff_graph* graph, const float* x,
                           const float* pos, const float* t, const int32_t* t_index_dev,
