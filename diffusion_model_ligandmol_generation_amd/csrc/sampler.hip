@@ -126,6 +126,43 @@ __global__ __launch_bounds__(256) void k_reverse_step(ligdiff_step_args a, int t
   state[j] = out;
 }
 
+// Coordinate-only update of the alternate samplers: pos <- (pos - b eps) / d + c z.
+__global__ __launch_bounds__(256) void k_pos_step(float* __restrict__ pos, const float* __restrict__ ec,
+                                                  const float* __restrict__ eu, float guidance_scale, int64_t n,
+                                                  float b, float d, float c, const float* __restrict__ noise,
+                                                  uint64_t seed, uint32_t step, int64_t elem_offset) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float eps = ec[i];
+  if (eu != nullptr) {
+    const float u = eu[i];
+    eps = u + guidance_scale * (eps - u);
+  }
+  float out = (pos[i] - eps * b) / d;
+  if (c != 0.0f) {
+    float z;
+    if (noise != nullptr) {
+      z = noise[i];
+    } else {
+      const uint64_t g = (uint64_t)(elem_offset + i);
+      z = philox_normal4(seed, step, 1u, g >> 2)[g & 3];
+    }
+    out += c * z;
+  }
+  pos[i] = out;
+}
+
+extern "C" int ligdiff_pos_step(float* pos, const float* eps_pos, const float* eps_pos_uncond, float guidance_scale,
+                                int64_t n_atoms, float b, float d, float c, const float* noise_pos, uint64_t seed,
+                                uint32_t step, int64_t atom_offset, void* stream) {
+  if (!pos || !eps_pos || n_atoms <= 0 || atom_offset < 0 || d == 0.0f) return LIGDIFF_ERR_ARG;
+  const int64_t n = n_atoms * 3;
+  hipLaunchKernelGGL(k_pos_step, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, pos, eps_pos,
+                     eps_pos_uncond, guidance_scale, n, b, d, c, noise_pos, seed, step, atom_offset * 3);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}
+
 __global__ void k_add_int(int32_t* p, int32_t d) { *p += d; }
 __global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
 

@@ -221,6 +221,15 @@ class ScoreNetworkEngine:
         with torch.cuda.device(self.device):
             check(self.lib.ligdiff_ddim_step(C.byref(args), int(t_cur), int(t_next), _stream()), "ligdiff_ddim_step")
 
+    def pos_step(self, pos, eps_pos, b, d, c, eps_pos_uncond=None, guidance_scale=1.0, noise_pos=None, seed=0,
+                 step=0, atom_offset=0):
+        """pos <- (pos - b * eps) / d + c * z in place (ligdiff_pos_step): the coordinate update of
+        the alternate samplers, model1.py:956-966 and train.py:855-863."""
+        with torch.cuda.device(self.device):
+            check(self.lib.ligdiff_pos_step(_ptr(pos), _ptr(eps_pos), _ptr(eps_pos_uncond), float(guidance_scale),
+                                            pos.shape[0], float(b), float(d), float(c), _ptr(noise_pos), int(seed),
+                                            int(step), int(atom_offset), _stream()), "ligdiff_pos_step")
+
     def ddpm_sample(self, model, graph, x, pos, properties=None, guidance_scale=1.0, temperature=1.0,
                     n_steps=None, seed=0, atom_offset=0, use_graph=True):
         """Whole reverse loop in the library (hipGraph replay); x / pos updated in place."""

@@ -97,5 +97,23 @@ class ResearchAccurateDiffusionModel(nn.Module):
                                                              classifier_free_guidance)
         return atom_pred, pos_pred, prop_pred, None
 
+    def sample(self, num_samples=1, target_properties=None, guidance_scale=1.0, num_steps=100, max_atoms=30,
+               seed=0):
+        """model1.py:890-978 without the RDKit post-processing (model1.py:980-1031, host code that
+        is not rebuilt): all ``num_samples`` molecules share each forward.  Returns one dict per
+        molecule with what the reference passes on to RDKit: 'positions' [k,3] and 'atom_types' [k]
+        for the first k = min(15, max_atoms) atoms (model1.py:991-997 clamps types to 1..8 and turns
+        a hydrogen that is not atom 0 into carbon), 'num_atoms' = k; there is no 'smiles' key."""
+        from .alt_samplers import ddim_positions
+        self.eval()
+        pos, atom_pred = ddim_positions(self, num_samples, target_properties, guidance_scale, num_steps, max_atoms,
+                                        seed)
+        k = min(15, max_atoms)
+        types = atom_pred.argmax(dim=-1).clamp(1, 8).view(num_samples, max_atoms)[:, :k].clone()
+        types[:, 1:][types[:, 1:] == 1] = 6
+        pos = pos.view(num_samples, max_atoms, 3)[:, :k].cpu().numpy()
+        types = types.cpu().numpy()
+        return [{"positions": pos[i], "atom_types": types[i], "num_atoms": k} for i in range(num_samples)]
+
 
 ResearchValidatedDiffusionModel = ResearchAccurateDiffusionModel  # model1.py:1035

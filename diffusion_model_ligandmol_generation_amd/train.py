@@ -248,5 +248,18 @@ class ResearchAccurateTrainer:
         torch.save(ckpt, os.path.join("research_checkpoints", name))
         torch.save(ckpt, os.path.join("research_checkpoints", "latest_checkpoint.pt"))
 
+    def generate_research_validated_molecules(self, num_samples=10, target_properties=None, guidance_scale=7.5,
+                                              num_steps=50, temperature=1.0, top_k=None, seed=0):
+        """train.py:786-892 without the RDKit post-processing (train.py:916-1036, host code with
+        random atom typing that is not rebuilt): 25-atom chain + ring graphs, EDM sigma schedule,
+        Euler coordinate updates, all molecules in one batch.  Returns one dict per molecule with
+        what the reference hands to RDKit: 'positions' [15,3] (train.py:927) and 'num_atoms'."""
+        from .alt_samplers import euler_positions
+        self.model.eval()
+        pos = euler_positions(self.model, num_samples, target_properties, guidance_scale, num_steps, temperature,
+                              25, seed)
+        pos = pos.view(num_samples, 25, 3)[:, :15].cpu().numpy()
+        return [{"positions": pos[i], "num_atoms": 15} for i in range(num_samples)]
+
 
 ResearchValidatedTrainer = ResearchAccurateTrainer

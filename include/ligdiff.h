@@ -228,6 +228,20 @@ int ligdiff_ddpm_step(const ligdiff_step_args* args, void* stream);
 /* DDIM: t_cur / t_next indices into alphas_cumprod; t_next < 0 means the final step. */
 int ligdiff_ddim_step(const ligdiff_step_args* args, int32_t t_cur, int32_t t_next, void* stream);
 
+/* Coordinate-only reverse update of the two alternate per-molecule samplers (atom features are
+ * never updated by them):   pos <- (pos - b * eps) / d + c * z
+ *   model1.py:956-966 (`sample`):   b = sqrt(1 - abar_t), d = sqrt(abar_t), c = sigma_t while the
+ *                                   next timestep is > 0, else 0; nothing on the last step;
+ *   train.py:855-863 (Euler, EDM):  b = sigma_t - sigma_next, d = 1,
+ *                                   c = 0.1 * sigma_next * temperature; nothing on the last step.
+ * eps = eps_pos, or eps_pos_uncond + guidance_scale * (eps_pos - eps_pos_uncond) when
+ * eps_pos_uncond is given (model1.py:948, train.py:850).  z = noise_pos [n_atoms,3] if given,
+ * else N(0,1) from the Philox stream 1 at (seed, step, 3 * atom_offset + element); no draw when
+ * c == 0.  The scalars are host values: both samplers step through a host-side schedule. */
+int ligdiff_pos_step(float* pos, const float* eps_pos, const float* eps_pos_uncond, float guidance_scale,
+                     int64_t n_atoms, float b, float d, float c, const float* noise_pos, uint64_t seed,
+                     uint32_t step, int64_t atom_offset, void* stream);
+
 /*
  * Whole 1000-step DDPM loop of generation.py:422-484 for a packed batch of molecules:
  * captures one reverse step (forward [+ unconditional forward] + fused update) into a

@@ -15,5 +15,6 @@ from .schedule import cosine_schedule, edm_scalings, edm_sigma_from_u, edm_loss_
 from .connectivity import template_connectivity  # noqa: F401
 from .packing import pack_csr, collate  # noqa: F401
 from .score_network import score_network_forward, fourier_time_embedding  # noqa: F401
-from .sampler import ddpm_sample, ddim_sample, validity_gate, ddpm_step  # noqa: F401
+from .sampler import (ddpm_sample, ddim_sample, validity_gate, ddpm_step, chain_edges,  # noqa: F401
+                      model_sample_positions, trainer_euler_positions, edm_sigma_steps)
 from .loss_step import loss_step  # noqa: F401

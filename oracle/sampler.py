@@ -158,3 +158,85 @@ def sample_molecule_size(atom_range, rng=np.random):
         tot = sum(p)
         return int(rng.choice(sizes, p=[q / tot for q in p]))
     return int(rng.randint(lo, hi))
+
+
+# ---------------------------------------------------------------------------------------
+# The two alternate per-molecule samplers.  Both only move the coordinates; the atom
+# features keep their initial Gaussian draw.
+
+def chain_edges(num_atoms, ring=False):
+    """Bond list of model1.py:917-920 (chain, both directions); with ring=True the trainer's
+    variant, train.py:894-914, which also closes atoms 0..5 into a ring when n >= 6."""
+    e = []
+    for i in range(num_atoms - 1):
+        e.extend([[i, i + 1], [i + 1, i]])
+    if ring and num_atoms >= 6:
+        for i in range(6):
+            j = (i + 1) % 6
+            if [i, j] not in e:
+                e.extend([[i, j], [j, i]])
+    if ring and len(e) == 0:
+        e = [[0, 1], [1, 0]]
+    return e
+
+
+def _predict_t(sd, x, pos, ei, batch, t_tensor, props, guidance_scale, max_atoms):
+    """model1.py:937-952 / train.py:841-853: unconditional + scale * (conditional - unconditional)
+    when guided, else one forward with the properties as given."""
+    if guidance_scale > 1.0 and props is not None:
+        au, pu, _ = score_network_forward(sd, x, pos, ei, batch, t_tensor, None, max_atoms=max_atoms)
+        ac, pc, _ = score_network_forward(sd, x, pos, ei, batch, t_tensor, props, max_atoms=max_atoms)
+        return au + guidance_scale * (ac - au), pu + guidance_scale * (pc - pu)
+    a, p, _ = score_network_forward(sd, x, pos, ei, batch, t_tensor, props, max_atoms=max_atoms)
+    return a, p
+
+
+def model_sample_positions(sd, sched, x0, pos0, noise, num_steps, target_properties=None,
+                           guidance_scale=1.0, max_atoms=100):
+    """model1.py:890-966 for ONE molecule up to (not including) the RDKit post-processing.
+
+    x0 [n,119], pos0 [n,3]: the initial draws; noise(shape) supplies each step's coordinate
+    noise in the reference's order.  Returns (pos, atom_pred of the last step)."""
+    n = x0.shape[0]
+    T = sched["betas"].shape[0]
+    ei = torch.tensor(chain_edges(n), dtype=torch.long).t().contiguous()
+    batch = torch.zeros(n, dtype=torch.long)
+    ts = torch.linspace(T - 1, 0, num_steps, dtype=torch.long)
+    ac = sched["alphas_cumprod"]
+    x, pos = x0, pos0
+    atom_pred = None
+    for i, t_val in enumerate(ts):
+        atom_pred, pos_pred = _predict_t(sd, x, pos, ei, batch, torch.tensor([int(t_val)]), target_properties,
+                                         guidance_scale, max_atoms)
+        if i < len(ts) - 1:
+            a_t, a_prev = ac[t_val], ac[ts[i + 1]]
+            sigma_t = ((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)).sqrt()
+            pos = (pos - pos_pred * (1 - a_t).sqrt()) / a_t.sqrt()
+            if ts[i + 1] > 0:
+                pos = pos + sigma_t * noise(tuple(pos.shape))
+    return pos, atom_pred
+
+
+def edm_sigma_steps(num_steps, sigma_min=0.002, sigma_max=80.0, rho=7.0):
+    """train.py:829-831."""
+    return (sigma_max ** (1 / rho) + torch.linspace(0, 1, num_steps + 1) *
+            (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+
+
+def trainer_euler_positions(sd, x0, pos0, noise, num_steps, target_properties=None, guidance_scale=7.5,
+                            temperature=1.0, sigma_min=0.002, sigma_max=80.0, rho=7.0, max_atoms=100):
+    """train.py:786-863 for ONE molecule up to the RDKit post-processing.  The model is
+    called with sigma_t as its time argument.  Returns pos."""
+    n = x0.shape[0]
+    ei = torch.tensor(chain_edges(n, ring=True), dtype=torch.long).t().contiguous()
+    batch = torch.zeros(n, dtype=torch.long)
+    sig = edm_sigma_steps(num_steps, sigma_min, sigma_max, rho)
+    x, pos = x0, pos0
+    for step in range(num_steps):
+        s_t, s_n = sig[step], sig[step + 1]
+        _, pos_pred = _predict_t(sd, x, pos, ei, batch, s_t.unsqueeze(0), target_properties, guidance_scale, max_atoms)
+        if step < num_steps - 1:
+            pos = pos - (s_t - s_n) * pos_pred
+            if temperature > 0 and s_n > 0:
+                pos = pos + s_n * (noise(tuple(pos.shape)) * temperature) * 0.1
+    return pos

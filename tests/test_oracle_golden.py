@@ -127,3 +127,36 @@ def test_pack_csr_small():
     assert p["perm"].tolist() == [1, 0, 3, 4, 2, 5]
     assert p["src"].tolist() == [1, 0, 2, 3, 1, 0]
     assert p["dst"].tolist() == [0, 1, 1, 1, 2, 3]
+
+
+@pytest.mark.parametrize("tag", ["ddim_plain", "ddim_cfg", "euler_plain", "euler_cfg"])
+def test_alternate_samplers_match_reference(tag):
+    """model1.py:890-966 and train.py:786-863 (coordinates handed to the post-processing)."""
+    f = golden("alt_samplers.npz")
+    S, n, steps, _ = [int(v) for v in f[tag + "_meta"]]
+    sd = seed0_state_dict()
+    sched = oracle.cosine_schedule(1000)
+    props = torch.from_numpy(f["props"]) if tag.endswith("cfg") else None
+    scale = float(f[tag + "_scale"])
+    if tag.startswith("euler"):
+        assert oracle.chain_edges(n, ring=True) == f[tag + "_edges"].T.tolist()
+    for m in range(S):
+        zs = iter(torch.from_numpy(f[tag + "_noise"][m]))
+        x0, p0 = torch.from_numpy(f[tag + "_x0"][m]), torch.from_numpy(f[tag + "_pos0"][m])
+        with torch.no_grad():
+            if tag.startswith("ddim"):
+                # the replayed noise tensor has one slot per step; noisy steps consume theirs in order
+                ts = torch.linspace(999, 0, steps, dtype=torch.long)
+                used = [i for i in range(steps) if i < steps - 1 and ts[i + 1] > 0]
+                zl = [torch.from_numpy(f[tag + "_noise"][m][i]) for i in used]
+                it = iter(zl)
+                pos, atom_pred = oracle.model_sample_positions(sd, sched, x0, p0, lambda shape: next(it), steps,
+                                                               props, scale)
+                torch.testing.assert_close(atom_pred, torch.from_numpy(f[tag + "_atom_pred"][m]), rtol=1e-4, atol=1e-4)
+            else:
+                pos = oracle.trainer_euler_positions(sd, x0, p0, lambda shape: next(zs), steps, props, scale,
+                                                     float(f[tag + "_temperature"]))
+        # the Euler sampler multiplies every prediction by (sigma_t - sigma_next), up to ~30 with
+        # sigma_max = 80, so rounding differences of the forward grow along the trajectory
+        tol = 2e-3 if tag.startswith("euler") else 1e-4
+        torch.testing.assert_close(pos, torch.from_numpy(f[tag + "_pos"][m]), rtol=tol, atol=tol)
