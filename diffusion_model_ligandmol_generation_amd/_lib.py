@@ -72,6 +72,12 @@ SIGNATURES = {
                                         C.c_size_t, C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_float)]),
     "ligdiff_ddpm_step": (C.c_int, [C.POINTER(StepArgs), C.c_void_p]),
     "ligdiff_ddim_step": (C.c_int, [C.POINTER(StepArgs), C.c_int32, C.c_int32, C.c_void_p]),
+    "ligdiff_forward_state_offsets": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int, C.POINTER(C.c_size_t),
+                                                C.POINTER(C.c_size_t)]),
+    "ligdiff_consistency_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "ligdiff_consistency": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
     "ligdiff_pos_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p]),
     "ligdiff_ddpm_sample_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int]),

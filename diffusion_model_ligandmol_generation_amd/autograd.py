@@ -19,7 +19,7 @@ def packed_graph_of(data):
     return g
 
 
-def score_network_apply(model, data, t, properties=None, classifier_free_guidance=False):
+def score_network_apply(model, data, t, properties=None, classifier_free_guidance=False, keep_state=False):
     if not hasattr(data, "batch") or data.batch is None:
         batch = torch.zeros(data.x.shape[0], dtype=torch.long, device=data.x.device)   # model1.py:702
         data.batch = batch
@@ -28,5 +28,7 @@ def score_network_apply(model, data, t, properties=None, classifier_free_guidanc
     needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     if needs_grad:
         from .backward import ScoreNetworkFunction
-        return ScoreNetworkFunction.run(model, eng, graph, data.x, data.pos, t, properties, classifier_free_guidance)
-    return eng.forward(graph, data.x, data.pos, t, properties, null_cond=classifier_free_guidance)
+        return ScoreNetworkFunction.run(model, eng, graph, data.x, data.pos, t, properties, classifier_free_guidance,
+                                        keep_state)
+    return eng.forward(graph, data.x, data.pos, t, properties, null_cond=classifier_free_guidance,
+                       keep_state=keep_state)

@@ -9,6 +9,12 @@ from ._lib import check
 from .engine import _ptr, _stream
 
 
+def _has_grad_slot(name):
+    """Table entries that take part in the score network's backward: not the frequency table and
+    not the consistency module, whose outputs reach no loss (train.py:519, :543, :559, :583)."""
+    return name != "__time_freqs__" and not name.startswith("moldiff_consistency.")
+
+
 class _Ctx:
     """Non-tensor state handed to the autograd Functions."""
 
@@ -34,6 +40,7 @@ class ScoreNetworkFunction(torch.autograd.Function):
                                      _stream())
         check(rc, "ligdiff_forward(save)")
         ctx.st, ctx.ws, ctx.flags = st, ws, flags
+        st.eng.last_forward = (ws, flags) if st.keep_state else None   # for consistency() right after this call
         ctx.param_shapes = [p.shape for p in params]
         ctx.set_materialize_grads(False)
         return atom, posp, prop
@@ -51,11 +58,11 @@ class ScoreNetworkFunction(torch.autograd.Function):
         table = (C.c_void_p * len(eng.names))()
         gi = 0
         for i, name in enumerate(eng.names):
-            if name == "__time_freqs__":
-                table[i] = None
-            else:
+            if _has_grad_slot(name):
                 table[i] = grads[gi].data_ptr()
                 gi += 1
+            else:
+                table[i] = None
         nbytes = lib.ligdiff_backward_workspace_bytes(N, graph.n_edges, B)
         bws = eng.workspace(nbytes)
         with torch.cuda.device(dev):
@@ -69,7 +76,7 @@ class ScoreNetworkFunction(torch.autograd.Function):
         has_props = bool(ctx.flags & _lib.FWD_PROPERTIES)
         null_cond = bool(ctx.flags & _lib.FWD_NULL_COND)
         out = []
-        pnames = [n for n in eng.names if n != "__time_freqs__"]
+        pnames = [n for n in eng.names if _has_grad_slot(n)]
         for name, gten in zip(pnames, grads):
             used = True
             if name == "property_guidance.null_embedding":
@@ -82,7 +89,7 @@ class ScoreNetworkFunction(torch.autograd.Function):
         return (None, *out)
 
     @staticmethod
-    def run(model, eng, graph, x, pos, t, properties, null_cond):
+    def run(model, eng, graph, x, pos, t, properties, null_cond, keep_state=False):
         N, B = graph.n_atoms, graph.n_mols
         x = x.detach().contiguous().float()
         pos = pos.detach().contiguous().float()
@@ -102,8 +109,8 @@ class ScoreNetworkFunction(torch.autograd.Function):
                 if props.shape != (B, 15):
                     raise ValueError("properties must be [B,15]")
         sd = dict(model.state_dict(keep_vars=True))
-        params = [sd[n] for n in eng.names if n != "__time_freqs__"]
-        st = _Ctx(eng=eng, graph=graph, x=x, pos=pos, t=t, props=props, flags=flags)
+        params = [sd[n] for n in eng.names if _has_grad_slot(n)]
+        st = _Ctx(eng=eng, graph=graph, x=x, pos=pos, t=t, props=props, flags=flags, keep_state=keep_state)
         return ScoreNetworkFunction.apply(st, *params)
 
 

@@ -104,3 +104,13 @@ extern "C" int ligdiff_forward_timed(const float* const* weights, const ligdiff_
   *mean_ms_host = (float)(total / reps);
   return rc;
 }
+
+extern "C" int ligdiff_forward_state_offsets(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int flags,
+                                             size_t* hidden_offset, size_t* pos_offset) {
+  if (n_atoms <= 0 || n_edges < 0 || n_mols <= 0 || !hidden_offset || !pos_offset) return LIGDIFF_ERR_ARG;
+  FwdLayout L;
+  fwd_layout(&L, n_atoms, n_edges, n_mols, flags);
+  *hidden_offset = L.x2[2];
+  *pos_offset = L.pos_cur;
+  return LIGDIFF_OK;
+}

@@ -94,7 +94,9 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (!w || !gr || !g || !x || !pos || !d_atom || !d_pos || !fwd_workspace || !workspace) return LIGDIFF_ERR_ARG;
   if (!(flags & LIGDIFF_FWD_SAVE_FOR_BACKWARD) || (flags & LIGDIFF_FWD_T_BROADCAST)) return LIGDIFF_ERR_ARG;
-  for (int i = 0; i < W_COUNT; ++i)
+  // every slot of the score network needs a gradient buffer; the frequency table and the consistency
+  // module (slots from W_CONS_0 on: no loss reaches it) have none
+  for (int i = 0; i < W_CONS_0; ++i)
     if (w[i] == nullptr || (i != W_TIME_FREQS && gr[i] == nullptr)) return LIGDIFF_ERR_ARG;
   const int N = (int)g->n_atoms, E = (int)g->n_edges, B = g->n_mols;
   FwdLayout F;

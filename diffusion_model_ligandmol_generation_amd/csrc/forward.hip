@@ -88,98 +88,32 @@ const WeightInfo* weight_table() {
       snprintf(f, sizeof f, "%s.3.bias", heads[h]);   wt_set(t, W_HEAD(h, HEAD_B3), outs[h], f);
     }
     wt_set(t, W_TIME_FREQS, 128, "__time_freqs__");
+    {
+      const char* pred[3] = {"atom_predictor", "bond_predictor", "valency_predictor"};
+      const int in0[3] = {256, 516, 375}, last_layer[3] = {6, 6, 5}, last_out[3] = {119, 5, 1};
+      for (int p = 0; p < 3; ++p) {
+        char f[96];
+        snprintf(f, sizeof f, "moldiff_consistency.%s.0.weight", pred[p]); wt_set(t, W_CONS(p, CONS_W0), 256 * in0[p], f);
+        snprintf(f, sizeof f, "moldiff_consistency.%s.0.bias", pred[p]);   wt_set(t, W_CONS(p, CONS_B0), 256, f);
+        snprintf(f, sizeof f, "moldiff_consistency.%s.2.weight", pred[p]); wt_set(t, W_CONS(p, CONS_G), 256, f);
+        snprintf(f, sizeof f, "moldiff_consistency.%s.2.bias", pred[p]);   wt_set(t, W_CONS(p, CONS_BE), 256, f);
+        snprintf(f, sizeof f, "moldiff_consistency.%s.3.weight", pred[p]); wt_set(t, W_CONS(p, CONS_W3), 128 * 256, f);
+        snprintf(f, sizeof f, "moldiff_consistency.%s.3.bias", pred[p]);   wt_set(t, W_CONS(p, CONS_B3), 128, f);
+        snprintf(f, sizeof f, "moldiff_consistency.%s.%d.weight", pred[p], last_layer[p]);
+        wt_set(t, W_CONS(p, CONS_WL), last_out[p] * 128, f);
+        snprintf(f, sizeof f, "moldiff_consistency.%s.%d.bias", pred[p], last_layer[p]);
+        wt_set(t, W_CONS(p, CONS_BL), last_out[p], f);
+      }
+      wt_set(t, W_CONS_MAXVAL, 119, "moldiff_consistency.max_valences");
+      wt_set(t, W_CONS_RADII, 119, "moldiff_consistency.covalent_radii");
+    }
     return true;
   }();
   (void)once;
   return tab;
 }
 
-// ------------------------------------------------------------------ launch helpers
-template <int NT, int WMODE, class AL, class EPI>
-static void launch_gemm(const GemmCore& g, const AL& al, const EPI& epi, int nb, hipStream_t s) {
-  if (g.M <= 0) return;
-  dim3 grid(ceil_div(g.M, G_BM), nb);
-  hipLaunchKernelGGL((gemm_rows_kernel<NT, WMODE, AL, EPI>), grid, dim3(256), 0, s, g, al, epi);
-}
-
-// LDS-DMA main loop (gemm2.h) unless LIGDIFF_GEMM_V1 is set in the environment (A/B switch).
-static bool use_gemm2() {
-  static const bool v = getenv("LIGDIFF_GEMM_V1") == nullptr;
-  return v;
-}
-// Eight-wave column-split kernel (gemm3.h) for 256-column blocks unless LIGDIFF_GEMM_NOCS is set.
-static bool use_cs() {
-  static const bool v = getenv("LIGDIFF_GEMM_NOCS") == nullptr && getenv("LIGDIFF_GEMM_V1") == nullptr;
-  return v;
-}
-template <class AP, class EPI>
-static void launch_gemm_cs(const GemmCore& g, const AP& ap, const EPI& epi, int nb, hipStream_t s) {
-  if (g.M <= 0) return;
-  hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);
-}
-template <int NT, class EPI>
-static void launch_gemm_plain(const GemmCore& g, const float* A, int lda, const EPI& epi, int nb, hipStream_t s) {
-  if (g.M <= 0) return;
-  dim3 grid(ceil_div(g.M, G_BM), nb);
-  if constexpr (NT == 8) {
-    if (use_cs() && (g.K % G2_BK) == 0 && (lda % 4) == 0 && (g.ldw % 4) == 0 && g.n_valid == 256) {
-      launch_gemm_cs(g, APtrPlain{A, lda}, epi, nb, s);
-      return;
-    }
-  }
-  if (use_gemm2() && (g.K % G2_BK) == 0 && (lda % 4) == 0 && (g.ldw % 4) == 0) {
-    APtrPlain ap{A, lda};
-    hipLaunchKernelGGL((gemm_rows2_kernel<NT, APtrPlain, EPI>), grid, dim3(256), 0, s, g, ap, epi);
-  } else {
-    ALoadPlain al{A, lda, g.M, g.K};
-    hipLaunchKernelGGL((gemm_rows_kernel<NT, W_ALIGNED, ALoadPlain, EPI>), grid, dim3(256), 0, s, g, al, epi);
-  }
-}
-
-static GemmCore core_blocks(int M, int K, int n_valid, const float* W, int ldw, int nb, int rows_per_block) {
-  GemmCore g;
-  memset(&g, 0, sizeof g);
-  g.M = M; g.K = K; g.n_valid = n_valid; g.ldw = ldw;
-  for (int i = 0; i < nb && i < 8; ++i) g.W[i] = W + (size_t)i * rows_per_block * ldw;
-  return g;
-}
-
-// y[M, nb*256] = act(A[M,K] W^T + b).  Plain bias/activation epilogues need no full rows, so
-// they run as 128-column blocks: twice the workgroups with half the accumulators each, which
-// keeps four or more workgroups resident per CU and lets one's epilogue (activation + stores)
-// overlap another's MFMA loop.
-template <int ACT, bool DUAL>
-static void gemm_bias_act(const float* A, int lda, int M, int K, const float* W, int ldw, const float* bias,
-                          int nb, float* C, int ldc, float* C2, hipStream_t s, float* pre_out = nullptr) {
-  const int nb4 = nb * 2;
-  if (use_cs() && (K % G2_BK) == 0 && (lda % 4) == 0 && (ldw % 4) == 0) {
-    GemmCore g = core_blocks(M, K, 256, W, ldw, nb, 256);
-    EpiBiasAct<8, ACT, DUAL> e;
-    memset(&e, 0, sizeof e);
-    e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = ldc; e.C2 = C2; e.alpha = 1.0f;
-    e.pre_out = pre_out;
-    for (int i = 0; i < nb; ++i) e.bias[i] = bias ? bias + (size_t)i * 256 : nullptr;
-    launch_gemm_cs(g, APtrPlain{A, lda}, e, nb, s);
-    return;
-  }
-  if (nb4 <= 8 && use_gemm2()) {
-    GemmCore g = core_blocks(M, K, 128, W, ldw, nb4, 128);
-    EpiBiasAct<4, ACT, DUAL> e;
-    memset(&e, 0, sizeof e);
-    e.M = M; e.n_valid = 128; e.col_block = 128; e.C = C; e.ldc = ldc; e.C2 = C2; e.alpha = 1.0f;
-    e.pre_out = pre_out;
-    for (int i = 0; i < nb4; ++i) e.bias[i] = bias ? bias + (size_t)i * 128 : nullptr;
-    launch_gemm_plain<4>(g, A, lda, e, nb4, s);
-    return;
-  }
-  GemmCore g = core_blocks(M, K, 256, W, ldw, nb, 256);
-  EpiBiasAct<8, ACT, DUAL> e;
-  memset(&e, 0, sizeof e);
-  e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = ldc; e.C2 = C2; e.alpha = 1.0f;
-  e.pre_out = pre_out;
-  for (int i = 0; i < nb; ++i) e.bias[i] = bias ? bias + (size_t)i * 256 : nullptr;
-  launch_gemm_plain<8>(g, A, lda, e, nb, s);
-}
+#include "launch.h"
 
 // ------------------------------------------------------------------ workspace layout
 void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {

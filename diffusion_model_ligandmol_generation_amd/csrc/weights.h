@@ -26,8 +26,16 @@ enum {
   HEAD_W0 = 0, HEAD_B0, HEAD_G, HEAD_BE, HEAD_W3, HEAD_B3,
   HEAD_SLOTS,
   W_TIME_FREQS = W_HEAD_0 + 3 * HEAD_SLOTS,  // not a state_dict entry: 128 Fourier frequencies
+  // moldiff_consistency.* (model1.py:383-414): three predictors x {0.w, 0.b, 2.w(LN), 2.b(LN), 3.w, 3.b,
+  // last.w, last.b} (last = layer 6 for atom / bond, layer 5 for valency) + the two chemistry buffers
+  W_CONS_0,
+  CONS_W0 = 0, CONS_B0, CONS_G, CONS_BE, CONS_W3, CONS_B3, CONS_WL, CONS_BL,
+  CONS_SLOTS,
+  W_CONS_MAXVAL = W_CONS_0 + 3 * CONS_SLOTS, W_CONS_RADII,
   W_COUNT
 };
+enum { CONS_ATOM = 0, CONS_BOND = 1, CONS_VAL = 2 };
+#define W_CONS(p, s) (W_CONS_0 + (p) * CONS_SLOTS + (s))
 
 #define W_E3(l, s) (W_E3_0 + (l) * E3_SLOTS + (s))
 #define W_DIT(l, s) (W_DIT_0 + (l) * DIT_SLOTS + (s))

@@ -126,7 +126,7 @@ class ScoreNetworkEngine:
         return self._ws
 
     def forward(self, graph, x, pos, t, properties=None, null_cond=False, want_props=True, save=False,
-                workspace=None, t_index=None):
+                workspace=None, t_index=None, keep_state=False):
         """ligdiff_forward on the current stream.  t: [B] float tensor (or [1], applied to
         every molecule); alternatively t_index, a device int32 scalar holding the step.
         Returns atom_pred, pos_pred, prop_pred (None if not wanted)."""
@@ -179,6 +179,7 @@ class ScoreNetworkEngine:
                                           flags, _ptr(atom_pred), _ptr(pos_pred), _ptr(prop_pred), _ptr(ws),
                                           ws.numel(), _stream())
         check(rc, "ligdiff_forward")
+        self.last_forward = (ws, flags) if keep_state else None   # for consistency() right after this call
         return atom_pred, pos_pred, prop_pred
 
     def time_launch(self, label, graph, x, pos, t_index, reps=5):
@@ -220,6 +221,35 @@ class ScoreNetworkEngine:
     def ddim_step(self, args, t_cur, t_next):
         with torch.cuda.device(self.device):
             check(self.lib.ligdiff_ddim_step(C.byref(args), int(t_cur), int(t_next), _stream()), "ligdiff_ddim_step")
+
+    def consistency(self, graph, ws, flags):
+        """MolDiff consistency outputs (model1.py:750-753) from the state a forward call left in
+        its workspace ``ws`` (called with ``flags``).  Returns the reference's 4-tuple
+        (atom_logits [N,119], bond_logits [P,5] or None, valency_constrained [N,N],
+        adjacency [B,n_max,n_max,5]); none of them carries gradient."""
+        lib, dev = self.lib, self.device
+        N, B = graph.n_atoms, graph.n_mols
+        h_off, p_off = C.c_size_t(0), C.c_size_t(0)
+        check(lib.ligdiff_forward_state_offsets(N, graph.n_edges, B, int(flags), C.byref(h_off), C.byref(p_off)),
+              "ligdiff_forward_state_offsets")
+        sizes = (graph.mol_ptr[1:] - graph.mol_ptr[:-1]).to(torch.int64)
+        pair_ptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        pair_ptr[1:] = torch.cumsum(sizes * (sizes - 1), 0)
+        n_pairs = int(pair_ptr[-1].item())
+        n_max = graph.max_mol_atoms
+        atom_logits = torch.empty(N, 119, dtype=torch.float32, device=dev)
+        bond_logits = torch.empty(n_pairs, 5, dtype=torch.float32, device=dev) if n_pairs > 0 else None
+        valency = torch.empty(N, N, dtype=torch.float32, device=dev)
+        adjacency = torch.empty(B, n_max, n_max, 5, dtype=torch.float32, device=dev)
+        cws = torch.empty(lib.ligdiff_consistency_workspace_bytes(N, n_pairs), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.ligdiff_consistency(self.table, C.byref(graph.c), ws.data_ptr() + h_off.value,
+                                         ws.data_ptr() + p_off.value, _ptr(pair_ptr), n_pairs, n_max,
+                                         _ptr(atom_logits), _ptr(bond_logits), _ptr(valency), _ptr(adjacency),
+                                         _ptr(cws), cws.numel(), _stream())
+        check(rc, "ligdiff_consistency")
+        self.last_forward = None
+        return atom_logits, bond_logits, valency, adjacency
 
     def pos_step(self, pos, eps_pos, b, d, c, eps_pos_uncond=None, guidance_scale=1.0, noise_pos=None, seed=0,
                  step=0, atom_offset=0):

@@ -87,15 +87,27 @@ class ResearchAccurateDiffusionModel(nn.Module):
         .edge_index [2,E] int64 and .batch [N] int64 (sorted).  Returns
         (atom_pred [N,119], pos_pred [N,3], prop_pred [B,15], consistency_outputs).
 
-        consistency_outputs is always None: the MolDiff consistency module only runs in
-        train mode in the reference (model1.py:750-753) and none of its outputs reaches
-        a loss with the data pipeline's batches (train.py:519, :543, :559, :583).
+        consistency_outputs: None in eval mode; in train mode the MolDiff consistency module's
+        (atom_logits, bond_logits, valency_constrained, adjacency_matrix) as model1.py:750-753
+        returns them, computed without dropout and detached (none of them reaches a loss with
+        the data pipeline's batches: train.py:519, :543, :559, :583).  A true
+        ``data.skip_consistency`` (the attribute model1.py:928 attaches) or
+        ``model.skip_consistency`` leaves it out: its [N,N] valency output is quadratic in the
+        batch's atom count.
         Errors raise instead of being turned into zero predictions (model1.py:757-764).
         """
-        from .autograd import score_network_apply
+        from .autograd import packed_graph_of, score_network_apply
+        want_cons = (self.training and not getattr(self, "skip_consistency", False)
+                     and not getattr(data, "skip_consistency", False))
         atom_pred, pos_pred, prop_pred = score_network_apply(self, data, t, properties,
-                                                             classifier_free_guidance)
-        return atom_pred, pos_pred, prop_pred, None
+                                                             classifier_free_guidance, keep_state=want_cons)
+        cons = None
+        if want_cons:
+            eng = self.engine()
+            ws, flags = eng.last_forward
+            with torch.no_grad():
+                cons = eng.consistency(packed_graph_of(data), ws, flags)
+        return atom_pred, pos_pred, prop_pred, cons
 
     def sample(self, num_samples=1, target_properties=None, guidance_scale=1.0, num_steps=100, max_atoms=30,
                seed=0):

@@ -122,6 +122,9 @@ class ResearchAccurateTrainer:
 
         d = _Data()
         d.x, d.pos, d.edge_index, d.batch, d._ligdiff_graph = x, pre_pos, batch.edge_index, batch.batch, graph
+        # the consistency module's outputs reach no loss term here (train.py:519, :543, :559, :583), so the
+        # training step does not spend an O(sum n^2) pass and an [N,N] tensor on them
+        d.skip_consistency = not getattr(self, "run_consistency", False)
         atom_pred, pos_pred, prop_pred, _ = model(d, c_noise, properties)               # train.py:349
 
         # global counts for data-parallel means

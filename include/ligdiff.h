@@ -129,7 +129,8 @@ int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, con
  * with LIGDIFF_FWD_SAVE_FOR_BACKWARD (per-molecule t, same graph / x / pos / properties /
  * flags).  grads: host array in the weights-table order of device pointers to PRE-ZEROED
  * fp32 tensors shaped like the weights; parameter gradients are ACCUMULATED into them
- * (float atomics over row splits, so the last bits vary from run to run).
+ * (float atomics over row splits, so the last bits vary from run to run).  The entries of
+ * "__time_freqs__" and of the moldiff_consistency.* slots may be NULL: no loss reaches them.
  * d_atom [N,119], d_pos [N,3], d_prop [B,15] (NULL = no gradient through prop_pred).
  * ------------------------------------------------------------------------------- */
 size_t ligdiff_backward_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols);
@@ -184,6 +185,26 @@ int ligdiff_loss_partial(const ligdiff_loss_args* args, float* sums8, void* stre
  * into d_atom [N,119], d_pos [N,3], d_prop [B,15] (d_prop may be NULL). */
 int ligdiff_loss_finish(const ligdiff_loss_args* args, const float* sums8, float upstream,
                         float* losses32, float* d_atom, float* d_pos, float* d_prop, void* stream);
+
+/* Byte offsets, inside the workspace of a completed ligdiff_forward call with the same sizes and
+ * flags, of the final hidden state h [n_atoms,256] (model1.py:738) and of pos + pos_updates
+ * [n_atoms,3] (model1.py:752): the two inputs of the consistency module. */
+int ligdiff_forward_state_offsets(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int flags,
+                                  size_t* hidden_offset, size_t* pos_offset);
+
+/* MolDiff consistency module, train-mode fourth output of the model (model1.py:750-753, :453-561),
+ * batched: the reference's Python double loop over atom pairs becomes row GEMMs over all ordered
+ * pairs.  pair_ptr [n_mols+1] (device, int64): exclusive prefix sum of n_m (n_m - 1); the pairs of
+ * molecule m are ordered (i, j != i) row-major as the loop at model1.py:513-540 visits them.
+ * Outputs: atom_logits [N,119]; bond_logits [n_pairs,5] (may be NULL when n_pairs == 0);
+ * valency [N,N] with valency[i,j] = min(valency_pred[j], max_valences[argmax_i]) - the [N] x [N,1]
+ * broadcast of model1.py:468; adjacency [n_mols, n_max, n_max, 5]: softmax bond probabilities,
+ * [1,0,0,0,0] on the diagonal of real atoms, zeros in the padding.  Dropout is not applied. */
+size_t ligdiff_consistency_workspace_bytes(int64_t n_atoms, int64_t n_pairs);
+int ligdiff_consistency(const float* const* weights, const ligdiff_graph* graph, const float* h, const float* pos,
+                        const int64_t* pair_ptr, int64_t n_pairs, int32_t n_max, float* atom_logits,
+                        float* bond_logits, float* valency, float* adjacency, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* Measurement hook (no counterpart in the reference): runs `reps` forwards and returns in
  * *mean_ms_host (host pointer) the mean duration, from HIP events recorded on `stream`, of

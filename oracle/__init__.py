@@ -18,3 +18,4 @@ from .score_network import score_network_forward, fourier_time_embedding  # noqa
 from .sampler import (ddpm_sample, ddim_sample, validity_gate, ddpm_step, chain_edges,  # noqa: F401
                       model_sample_positions, trainer_euler_positions, edm_sigma_steps)
 from .loss_step import loss_step  # noqa: F401
+from .consistency import consistency_forward  # noqa: F401,E402

@@ -105,5 +105,41 @@ def main():
     print("written", os.path.join(HERE, "alt_samplers.npz"))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--consistency" not in sys.argv:
     main()
+
+
+def consistency_fixture():
+    """Train-mode forward of the reference with every dropout at p = 0: the 4th return value
+    (MolDiff consistency outputs, model1.py:750-753).  The two chemistry buffers are stored as
+    inputs: without RDKit they hold the loader's placeholder table."""
+    from make_golden import template_batch
+    m1, tr, gen = _ref_loader.load_reference()
+    Data = sys.modules["torch_geometric.data"].Data
+    model = build_model(m1)
+    for lyr in model.dit_layers:
+        lyr.attention.dropout = 0.0
+        lyr.ff_network[2].p = 0.0
+        lyr.ff_network[4].p = 0.0
+    model.moldiff_consistency.atom_predictor[5].p = 0.0
+    model.moldiff_consistency.bond_predictor[5].p = 0.0
+    model.train()
+    g = torch.Generator().manual_seed(31)
+    sizes = [5, 9, 2, 7]
+    x, pos, ei, b = template_batch(gen.ResearchValidatedGenerator, sizes, g)
+    t = torch.tensor([10.0, 500.0, 900.0, 42.0])
+    with torch.no_grad():
+        out = run_checked(lambda: model(Data(x=x, pos=pos, edge_index=ei, edge_attr=None, batch=b), t))
+    atom_pred, pos_pred, prop_pred, cons = out
+    assert cons is not None and cons[1] is not None
+    np.savez_compressed(
+        os.path.join(HERE, "consistency.npz"), sizes=np.array(sizes), x=x.numpy(), pos=pos.numpy(),
+        edge_index=ei.numpy(), batch=b.numpy(), t=t.numpy(), atom_pred=atom_pred.numpy(), pos_pred=pos_pred.numpy(),
+        max_valences=model.moldiff_consistency.max_valences.numpy(),
+        covalent_radii=model.moldiff_consistency.covalent_radii.numpy(),
+        atom_logits=cons[0].numpy(), bond_logits=cons[1].numpy(), valency=cons[2].numpy(), adjacency=cons[3].numpy())
+    print("written consistency.npz", [tuple(c.shape) for c in cons])
+
+
+if __name__ == "__main__" and "--consistency" in sys.argv:
+    consistency_fixture()

@@ -117,3 +117,45 @@ def test_pack_rejects_unsorted_batch_and_bad_edges():
         PackedGraph(ei, torch.tensor([0, 1, 0]).cuda())
     with pytest.raises(LigdiffError):
         PackedGraph(torch.tensor([[0, 5], [1, 0]]).cuda(), torch.tensor([0, 0, 0]).cuda())
+
+
+def test_consistency_outputs_match_reference_fixture():
+    """Train-mode fourth output of the model (model1.py:750-753, :453-561) through
+    ligdiff_consistency, against the reference's own outputs (dropout p = 0)."""
+    import copy
+    f = golden("consistency.npz")
+    m = copy.deepcopy(seed0_model()).cuda()
+    m.moldiff_consistency.max_valences.copy_(torch.from_numpy(f["max_valences"]))
+    m.moldiff_consistency.covalent_radii.copy_(torch.from_numpy(f["covalent_radii"]))
+    x, pos, ei, b, t = _to(f, ("x", "pos", "edge_index", "batch", "t"))
+    m.train()
+    with torch.no_grad():
+        a, p, r, cons = m(Bag(x=x, pos=pos, edge_index=ei, batch=b), t)
+    assert cons is not None and len(cons) == 4
+    torch.testing.assert_close(a.cpu(), torch.from_numpy(f["atom_pred"]), rtol=RTOL, atol=ATOL)
+    for got, key in zip(cons, ("atom_logits", "bond_logits", "valency", "adjacency")):
+        torch.testing.assert_close(got.cpu(), torch.from_numpy(f[key]), rtol=RTOL, atol=ATOL)
+    # with autograd on (a training step's forward) the same outputs come back, detached
+    a2, p2, r2, cons2 = m(Bag(x=x, pos=pos, edge_index=ei, batch=b), t)
+    assert a2.requires_grad and not cons2[0].requires_grad
+    torch.testing.assert_close(cons2[3], cons[3], rtol=1e-5, atol=1e-6)
+    m.eval()
+    with torch.no_grad():
+        assert m(Bag(x=x, pos=pos, edge_index=ei, batch=b), t)[3] is None
+
+
+def test_consistency_batched_matches_oracle_ragged():
+    """Larger ragged batch (several 32-row tiles of pairs) against the CPU restatement."""
+    import copy
+    m = copy.deepcopy(seed0_model()).cuda().train()
+    sd = seed0_state_dict()
+    c = _random_batch([29, 3, 17, 40, 2, 33], 5)
+    x, pos, ei, b = (torch.from_numpy(c[k]) for k in ("x", "pos", "edge_index", "batch"))
+    t = torch.tensor([3.0, 999.0, 500.0, 250.0, 0.0, 77.0])
+    with torch.no_grad():
+        _, _, _, inter = oracle.score_network_forward(sd, x, pos, ei, b, t, None, pad_to_max_atoms=False,
+                                                      return_intermediates=True)
+        want = oracle.consistency_forward(sd, inter["h_dit"], pos + inter["pos_updates"], b)
+        got = m(Bag(x=x.cuda(), pos=pos.cuda(), edge_index=ei.cuda(), batch=b.cuda()), t.cuda())[3]
+    for g_, w_ in zip(got, want):
+        torch.testing.assert_close(g_.cpu(), w_, rtol=RTOL, atol=ATOL)

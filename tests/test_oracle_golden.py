@@ -160,3 +160,18 @@ def test_alternate_samplers_match_reference(tag):
         # sigma_max = 80, so rounding differences of the forward grow along the trajectory
         tol = 2e-3 if tag.startswith("euler") else 1e-4
         torch.testing.assert_close(pos, torch.from_numpy(f[tag + "_pos"][m]), rtol=tol, atol=tol)
+
+
+def test_consistency_module_matches_reference():
+    """model1.py:453-561 on the train-mode forward's final hidden state (fixture: dropout p = 0)."""
+    f = golden("consistency.npz")
+    sd = dict(seed0_state_dict())
+    sd["moldiff_consistency.max_valences"] = torch.from_numpy(f["max_valences"])
+    sd["moldiff_consistency.covalent_radii"] = torch.from_numpy(f["covalent_radii"])
+    x, pos, ei, b, t = (torch.from_numpy(f[k]) for k in ("x", "pos", "edge_index", "batch", "t"))
+    with torch.no_grad():
+        a, p, _, inter = oracle.score_network_forward(sd, x, pos, ei, b, t, None, return_intermediates=True)
+        cons = oracle.consistency_forward(sd, inter["h_dit"], pos + inter["pos_updates"], b)
+    torch.testing.assert_close(a, torch.from_numpy(f["atom_pred"]), rtol=1e-4, atol=1e-5)
+    for got, key in zip(cons, ("atom_logits", "bond_logits", "valency", "adjacency")):
+        torch.testing.assert_close(got, torch.from_numpy(f[key]), rtol=1e-4, atol=1e-5)
