@@ -30,6 +30,17 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags);
 // Measurement hook: the launch whose label equals `label` is bracketed by e0 / e1.
 struct FwdProbe { const char* label; hipEvent_t e0, e1; int hits; };
 
+// Library-internal flag (not part of the C ABI): the shared-timestep buffers of the workspace
+// (temb [1,256] and the three adaLN rows mod[l] [1,1536]) were filled by the caller, so the forward
+// skips its time path.  Only meaningful together with LIGDIFF_FWD_T_BROADCAST.
+#define FWD_INTERNAL_TIME_GIVEN (1 << 20)
+
+// Time embedding + adaLN parameters for n_rows timesteps t[0..n_rows) with the kernels (and the
+// per-row summation order) of the shared-timestep path: temb [n,256], mod_l [n,1536];
+// tf [n,256], t1 [n,512], stemb [n,256] are scratch.
+int run_time_rows(const float* const* w, const float* t, int n_rows, float* tf, float* t1, float* temb,
+                  float* stemb, float* mod0, float* mod1, float* mod2, hipStream_t s);
+
 int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
                 const float* t, const int32_t* t_index_dev, const float* properties, int flags,
                 float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s,

@@ -163,6 +163,23 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
   L->total = off;
 }
 
+// ------------------------------------------------------------------ time path for a table of timesteps
+int run_time_rows(const float* const* w, const float* t, int n_rows, float* tf, float* t1, float* temb,
+                  float* stemb, float* mod0, float* mod1, float* mod2, hipStream_t s) {
+  if (n_rows <= 0) return LIGDIFF_ERR_ARG;
+  hipLaunchKernelGGL(k_fourier, dim3(n_rows), dim3(128), 0, s, t, (const int32_t*)nullptr, w[W_TIME_FREQS], tf);
+  SmallLinearSets p0 = {{w[W_T0_W]}, {w[W_T0_B]}, {t1}};
+  hipLaunchKernelGGL((k_small_linear<1, false>), dim3(128, 1), dim3(256), 0, s, tf, p0, (float*)nullptr, n_rows, 256, 512);
+  SmallLinearSets p2 = {{w[W_T2_W]}, {w[W_T2_B]}, {temb}};
+  hipLaunchKernelGGL((k_small_linear<0, true>), dim3(64, 1), dim3(256), 0, s, t1, p2, stemb, n_rows, 512, 256);
+  SmallLinearSets pa;
+  float* mods[3] = {mod0, mod1, mod2};
+  for (int l = 0; l < 3; ++l) { pa.W[l] = w[W_DIT(l, DIT_ADA_W)]; pa.b[l] = w[W_DIT(l, DIT_ADA_B)]; pa.C[l] = mods[l]; }
+  hipLaunchKernelGGL((k_small_linear<0, false>), dim3(384, 3), dim3(256), 0, s, stemb, pa, (float*)nullptr, n_rows, 256, 1536);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}
+
 // ------------------------------------------------------------------ the forward pass
 int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
                 const float* t, const int32_t* t_index_dev, const float* properties, int flags,
@@ -189,10 +206,12 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   const int mstride = (flags & LIGDIFF_FWD_T_BROADCAST) ? 0 : 1536;
 
   // --- time embedding (model1.py:705-706) and adaLN parameters (model1.py:288)
-  PB("time.fourier");
-  hipLaunchKernelGGL(k_fourier, dim3(Bt), dim3(128), 0, s, t, t_index_dev, w[W_TIME_FREQS], F(L.tf));
-  PE();
-  if (Bt <= 4 && !L.save) {  // shared step index: a few rows -> wave-per-output linears
+  if (flags & FWD_INTERNAL_TIME_GIVEN) {
+    if (!(flags & LIGDIFF_FWD_T_BROADCAST) || L.save) return LIGDIFF_ERR_ARG;
+  } else if (Bt <= 4 && !L.save) {  // shared step index: a few rows -> wave-per-output linears
+    PB("time.fourier");
+    hipLaunchKernelGGL(k_fourier, dim3(Bt), dim3(128), 0, s, t, t_index_dev, w[W_TIME_FREQS], F(L.tf));
+    PE();
     SmallLinearSets p0 = {{w[W_T0_W]}, {w[W_T0_B]}, {F(L.t1)}};
     PB("time.mlp0");
     hipLaunchKernelGGL((k_small_linear<1, false>), dim3(128, 1), dim3(256), 0, s, F(L.tf), p0, (float*)nullptr, Bt, 256, 512);
@@ -207,6 +226,9 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     hipLaunchKernelGGL((k_small_linear<0, false>), dim3(384, 3), dim3(256), 0, s, F(L.stemb), pa, (float*)nullptr, Bt, 256, 1536);
     PE();
   } else {
+    PB("time.fourier");
+    hipLaunchKernelGGL(k_fourier, dim3(Bt), dim3(128), 0, s, t, t_index_dev, w[W_TIME_FREQS], F(L.tf));
+    PE();
     PB("time.mlp0");
     gemm_bias_act<ACT_GELU, false>(F(L.tf), 256, Bt, 256, w[W_T0_W], 256, w[W_T0_B], 2, F(L.t1), 512, nullptr, s,
                                    S(L.t1_pre));

@@ -76,9 +76,52 @@ __device__ __forceinline__ StepCoef ddpm_coef(const float* betas, const float* a
   return k;
 }
 
-// One thread per element.  stream id 0 = atom features, 1 = coordinates.
-template <bool DDIM>
-__global__ __launch_bounds__(256) void k_reverse_step(ligdiff_step_args a, int t_cur_arg, int t_next_arg) {
+// One thread per QUAD of four consecutive global elements (one Philox call yields four normals;
+// a thread per element would compute each call four times).  stream id 0 = atom features,
+// 1 = coordinates; the quad index is global (atom_offset included), so the first and last quad of
+// an array may be partial.  Used for the DDPM update; the DDIM update draws no noise.
+__global__ __launch_bounds__(256) void k_reverse_step_ddpm(ligdiff_step_args a) {
+  const int64_t nx = a.n_atoms * LD_A, np = a.n_atoms * 3;
+  const int64_t gx0 = a.atom_offset * LD_A, gp0 = a.atom_offset * 3;
+  // quads covering [g0, g0 + n): from g0 >> 2 to (g0 + n - 1) >> 2
+  const int64_t qx = ((gx0 + nx - 1) >> 2) - (gx0 >> 2) + 1;
+  const int64_t qp = ((gp0 + np - 1) >> 2) - (gp0 >> 2) + 1;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= qx + qp) return;
+  const bool is_pos = i >= qx;
+  const int64_t g0 = is_pos ? gp0 : gx0, n = is_pos ? np : nx;
+  const uint64_t quad = (uint64_t)((g0 >> 2) + (is_pos ? i - qx : i));
+  float* state = is_pos ? a.pos : a.x;
+  const float* ec = is_pos ? a.eps_pos : a.eps_x;
+  const float* eu = is_pos ? a.eps_pos_uncond : a.eps_x_uncond;
+  const float* nz = is_pos ? a.noise_pos : a.noise_x;
+  const int t = *a.t_index_dev;
+  const StepCoef k = ddpm_coef(a.betas, a.alphas, a.alphas_cumprod, t, a.temperature);
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  if (t > 0 && k.add_noise && nz == nullptr) z = philox_normal4(a.seed, (uint32_t)t, is_pos ? 1u : 0u, quad);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t j = (int64_t)(quad * 4 + e) - g0;   // local element
+    if (j < 0 || j >= n) continue;
+    float eps = ec[j];
+    if (eu != nullptr) {  // generation.py:442-443
+      const float u = eu[j];
+      eps = u + a.guidance_scale * (eps - u);
+    }
+    const float v = state[j];
+    float out;
+    if (t > 0) {
+      out = k.a * (v - k.b * eps);
+      if (k.add_noise) out += ((nz != nullptr ? nz[j] : z[e]) * k.c) * a.temperature;
+    } else {
+      out = (v - k.b * eps) / k.c;
+    }
+    state[j] = out;
+  }
+}
+
+// DDIM update (generation.py:359-381), one thread per element.
+__global__ __launch_bounds__(256) void k_reverse_step_ddim(ligdiff_step_args a, int t_cur_arg, int t_next_arg) {
   const int64_t nx = a.n_atoms * LD_A, np = a.n_atoms * 3;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nx + np) return;
@@ -93,35 +136,12 @@ __global__ __launch_bounds__(256) void k_reverse_step(ligdiff_step_args a, int t
     eps = u + a.guidance_scale * (eps - u);
   }
   const float v = state[j];
-  float out;
-  if (DDIM) {
-    const float at = a.alphas_cumprod[t_cur_arg];
-    const float x0 = (v - sqrtf(1.0f - at) * eps) / sqrtf(at);
-    if (t_next_arg >= 0) {
-      const float an = a.alphas_cumprod[t_next_arg];
-      out = sqrtf(an) * x0 + sqrtf(1.0f - an) * eps;
-    } else {
-      out = x0;
-    }
-  } else {
-    const int t = *a.t_index_dev;
-    const StepCoef k = ddpm_coef(a.betas, a.alphas, a.alphas_cumprod, t, a.temperature);
-    if (t > 0) {
-      out = k.a * (v - k.b * eps);
-      if (k.add_noise) {
-        float z;
-        const float* nz = is_pos ? a.noise_pos : a.noise_x;
-        if (nz != nullptr) {
-          z = nz[j];
-        } else {
-          const uint64_t g = (uint64_t)(a.atom_offset * (is_pos ? 3 : LD_A) + j);
-          z = philox_normal4(a.seed, (uint32_t)t, is_pos ? 1u : 0u, g >> 2)[g & 3];
-        }
-        out += (z * k.c) * a.temperature;
-      }
-    } else {
-      out = (v - k.b * eps) / k.c;
-    }
+  const float at = a.alphas_cumprod[t_cur_arg];
+  const float x0 = (v - sqrtf(1.0f - at) * eps) / sqrtf(at);
+  float out = x0;
+  if (t_next_arg >= 0) {
+    const float an = a.alphas_cumprod[t_next_arg];
+    out = sqrtf(an) * x0 + sqrtf(1.0f - an) * eps;
   }
   state[j] = out;
 }
@@ -166,6 +186,11 @@ extern "C" int ligdiff_pos_step(float* pos, const float* eps_pos, const float* e
 __global__ void k_add_int(int32_t* p, int32_t d) { *p += d; }
 __global__ void k_set_int(int32_t* p, int32_t v) { *p = v; }
 
+static void launch_reverse_step_ddpm(const ligdiff_step_args* a, hipStream_t s) {
+  const int64_t quads = (a->n_atoms * LD_A + 3) / 4 + (a->n_atoms * 3 + 3) / 4 + 2;   // upper bound incl. partial ends
+  hipLaunchKernelGGL(k_reverse_step_ddpm, dim3(ceil_div(quads, 256)), dim3(256), 0, s, *a);
+}
+
 static int check_step_args(const ligdiff_step_args* a) {
   if (!a || !a->x || !a->pos || !a->eps_x || !a->eps_pos || a->n_atoms <= 0) return LIGDIFF_ERR_ARG;
   if ((a->eps_x_uncond == nullptr) != (a->eps_pos_uncond == nullptr)) return LIGDIFF_ERR_ARG;
@@ -178,8 +203,7 @@ extern "C" int ligdiff_ddpm_step(const ligdiff_step_args* a, void* stream) {
   if (rc) return rc;
   if (!a->betas || !a->alphas || !a->alphas_cumprod || !a->t_index_dev) return LIGDIFF_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t n = a->n_atoms * (LD_A + 3);
-  hipLaunchKernelGGL(k_reverse_step<false>, dim3(ceil_div(n, 256)), dim3(256), 0, s, *a, 0, 0);
+  launch_reverse_step_ddpm(a, s);
   hipLaunchKernelGGL(k_add_int, dim3(1), dim3(1), 0, s, a->t_index_dev, -1);
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;
@@ -190,14 +214,21 @@ extern "C" int ligdiff_ddim_step(const ligdiff_step_args* a, int32_t t_cur, int3
   if (rc) return rc;
   if (!a->alphas_cumprod || t_cur < 0) return LIGDIFF_ERR_ARG;
   const int64_t n = a->n_atoms * (LD_A + 3);
-  hipLaunchKernelGGL(k_reverse_step<true>, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, *a, t_cur, t_next);
+  hipLaunchKernelGGL(k_reverse_step_ddim, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, *a, t_cur, t_next);
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;
 }
 
 // ------------------------------------------------------------------ whole DDPM loop
-struct SampleLayout { size_t fwd, eps_x, eps_pos, eps_xu, eps_pu, t_index, total; };
-static void sample_layout(SampleLayout* L, int64_t N, int64_t E, int32_t B, int guided) {
+// The time embedding and the adaLN parameters depend on the step index only, so they are computed
+// for ALL steps before the loop (n_steps rows, same kernels and per-row arithmetic as the one-row
+// path); each step then copies its row into the forward's shared-timestep buffers with one small
+// launch that also advances the step counter.
+#define TIME_ROW_FLOATS (256 + 3 * 1536)
+struct SampleLayout {
+  size_t fwd, eps_x, eps_pos, eps_xu, eps_pu, t_index, tvals, tf, t1, stemb, tab_temb, tab_mod[3], total;
+};
+static void sample_layout(SampleLayout* L, int64_t N, int64_t E, int32_t B, int guided, int32_t n_steps) {
   FwdLayout F;
   fwd_layout(&F, N, E, B, LIGDIFF_FWD_T_BROADCAST);
   size_t off = 0;
@@ -207,13 +238,43 @@ static void sample_layout(SampleLayout* L, int64_t N, int64_t E, int32_t B, int 
   L->eps_xu = guided ? take((size_t)N * LD_A * 4) : 0;
   L->eps_pu = guided ? take((size_t)N * 3 * 4) : 0;
   L->t_index = take(256);
+  const size_t T = (size_t)(n_steps > 0 ? n_steps : 1);
+  L->tvals = take(T * 4); L->tf = take(T * 256 * 4); L->t1 = take(T * 512 * 4); L->stemb = take(T * 256 * 4);
+  L->tab_temb = take(T * 256 * 4);
+  for (int l = 0; l < 3; ++l) L->tab_mod[l] = take(T * 1536 * 4);
   L->total = off;
 }
 
-extern "C" size_t ligdiff_ddpm_sample_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided) {
+extern "C" size_t ligdiff_ddpm_sample_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided,
+                                                      int32_t n_steps) {
   SampleLayout L;
-  sample_layout(&L, n_atoms, n_edges, n_mols, guided);
+  sample_layout(&L, n_atoms, n_edges, n_mols, guided, n_steps);
   return L.total;
+}
+
+__global__ void k_iota_float(float* v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (float)i;
+}
+
+// Step prologue: row t = counter[0] of the tables -> the forward's temb / mod buffers.
+struct TimeGatherArgs { const float* tab_temb; const float* tab_mod[3]; float* temb; float* mod[3]; };
+__global__ __launch_bounds__(256) void k_time_gather(const int32_t* counter, TimeGatherArgs p) {
+  const int t = counter[0];
+  const int i = blockIdx.x * 256 + threadIdx.x;    // float4 index within the 4864-float row
+  if (i < 64) {
+    reinterpret_cast<f32x4*>(p.temb)[i] = reinterpret_cast<const f32x4*>(p.tab_temb + (size_t)t * 256)[i];
+  } else if (i < 64 + 3 * 384) {
+    const int l = (i - 64) / 384, j = (i - 64) % 384;
+    reinterpret_cast<f32x4*>(p.mod[l])[j] = reinterpret_cast<const f32x4*>(p.tab_mod[l] + (size_t)t * 1536)[j];
+  }
+}
+// counter[1] = index of the step now in progress (read by its update kernel), counter[0] = the next
+// one.  A launch of its own, after the gather: every block of the gather reads counter[0].
+__global__ void k_advance(int32_t* counter) {
+  const int t = counter[0];
+  counter[1] = t;
+  counter[0] = t - 1;
 }
 
 extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
@@ -227,65 +288,89 @@ extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_gr
   // generation.py:428: guidance only when properties are given AND scale > 1
   const int guided = (properties != nullptr && guidance_scale > 1.0f) ? 1 : 0;
   SampleLayout L;
-  sample_layout(&L, graph->n_atoms, graph->n_edges, graph->n_mols, guided);
+  sample_layout(&L, graph->n_atoms, graph->n_edges, graph->n_mols, guided, n_steps);
   if (workspace_bytes < L.total) return LIGDIFF_ERR_WORKSPACE;
   char* ws = (char*)workspace;
   hipStream_t s = (hipStream_t)stream;
-  int32_t* t_index = (int32_t*)(ws + L.t_index);
+  int32_t* counter = (int32_t*)(ws + L.t_index);   // [0] next step index, [1] index of the step in progress
+  auto WF = [&](size_t off) { return (float*)(ws + off); };
+
+  // tables for t = 0 .. n_steps-1
+  hipLaunchKernelGGL(k_iota_float, dim3(ceil_div(n_steps, 256)), dim3(256), 0, s, WF(L.tvals), n_steps);
+  int rc = run_time_rows(weights, WF(L.tvals), n_steps, WF(L.tf), WF(L.t1), WF(L.tab_temb), WF(L.stemb),
+                         WF(L.tab_mod[0]), WF(L.tab_mod[1]), WF(L.tab_mod[2]), s);
+  if (rc) return rc;
+  FwdLayout FL;
+  fwd_layout(&FL, graph->n_atoms, graph->n_edges, graph->n_mols, LIGDIFF_FWD_T_BROADCAST);
+  TimeGatherArgs tg;
+  tg.tab_temb = WF(L.tab_temb); tg.temb = WF(L.fwd + FL.temb);
+  for (int l = 0; l < 3; ++l) { tg.tab_mod[l] = WF(L.tab_mod[l]); tg.mod[l] = WF(L.fwd + FL.mod[l]); }
 
   ligdiff_step_args a;
   memset(&a, 0, sizeof a);
   a.x = x; a.pos = pos;
-  a.eps_x = (float*)(ws + L.eps_x); a.eps_pos = (float*)(ws + L.eps_pos);
-  if (guided) { a.eps_x_uncond = (float*)(ws + L.eps_xu); a.eps_pos_uncond = (float*)(ws + L.eps_pu); }
+  a.eps_x = WF(L.eps_x); a.eps_pos = WF(L.eps_pos);
+  if (guided) { a.eps_x_uncond = WF(L.eps_xu); a.eps_pos_uncond = WF(L.eps_pu); }
   a.guidance_scale = guidance_scale; a.temperature = temperature;
   a.betas = betas; a.alphas = alphas; a.alphas_cumprod = alphas_cumprod;
-  a.t_index_dev = t_index; a.seed = seed; a.atom_offset = atom_offset; a.n_atoms = graph->n_atoms;
+  a.t_index_dev = counter + 1; a.seed = seed; a.atom_offset = atom_offset; a.n_atoms = graph->n_atoms;
 
-  const int base = LIGDIFF_FWD_T_BROADCAST | LIGDIFF_FWD_SKIP_PROP_HEAD;
+  const int base = LIGDIFF_FWD_T_BROADCAST | LIGDIFF_FWD_SKIP_PROP_HEAD | FWD_INTERNAL_TIME_GIVEN;
   auto one_step = [&]() -> int {
-    int rc = run_forward(weights, graph, x, pos, nullptr, t_index, properties,
-                         base | (properties ? LIGDIFF_FWD_PROPERTIES : 0), (float*)(ws + L.eps_x),
-                         (float*)(ws + L.eps_pos), nullptr, ws + L.fwd, s);
-    if (rc) return rc;
+    hipLaunchKernelGGL(k_time_gather, dim3(5), dim3(256), 0, s, counter, tg);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, counter);
+    int r = run_forward(weights, graph, x, pos, nullptr, counter + 1, properties,
+                        base | (properties ? LIGDIFF_FWD_PROPERTIES : 0), WF(L.eps_x), WF(L.eps_pos), nullptr,
+                        ws + L.fwd, s);
+    if (r) return r;
     if (guided) {
-      rc = run_forward(weights, graph, x, pos, nullptr, t_index, nullptr, base, (float*)(ws + L.eps_xu),
-                       (float*)(ws + L.eps_pu), nullptr, ws + L.fwd, s);
-      if (rc) return rc;
+      r = run_forward(weights, graph, x, pos, nullptr, counter + 1, nullptr, base, WF(L.eps_xu), WF(L.eps_pu), nullptr,
+                      ws + L.fwd, s);
+      if (r) return r;
     }
-    return ligdiff_ddpm_step(&a, s);
+    launch_reverse_step_ddpm(&a, s);
+    return hipGetLastError() == hipSuccess ? LIGDIFF_OK : LIGDIFF_ERR_LAUNCH;
   };
 
-  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, t_index, n_steps - 1);
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, counter, n_steps - 1);
   if (!use_graph) {
     for (int i = 0; i < n_steps; ++i) {
-      int rc = one_step();
+      rc = one_step();
       if (rc) return rc;
     }
     return LIGDIFF_OK;
   }
-  // One reverse step is captured once; the step index lives in device memory and is
-  // decremented by the graph itself, so the same executable graph serves every step.
-  hipGraph_t graph_h = nullptr;
-  hipGraphExec_t exec = nullptr;
-  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return LIGDIFF_ERR_LAUNCH;
-  int rc = one_step();
-  hipError_t he = hipStreamEndCapture(s, &graph_h);
-  if (rc || he != hipSuccess || graph_h == nullptr) {
-    if (graph_h) (void)hipGraphDestroy(graph_h);
-    return rc ? rc : LIGDIFF_ERR_LAUNCH;
-  }
-  if (hipGraphInstantiate(&exec, graph_h, nullptr, nullptr, 0) != hipSuccess) {
-    (void)hipGraphDestroy(graph_h);
-    return LIGDIFF_ERR_LAUNCH;
-  }
+  // The step counter lives in device memory and is advanced by the captured kernels themselves, so
+  // one executable graph serves every step.  Four steps are captured per graph (fewer graph launch
+  // boundaries, each worth ~8 us of idle GPU); a one-step graph runs the remainder.
+  const int kGroup = 4;
+  auto capture = [&](int steps, hipGraphExec_t* exec_out) -> int {
+    hipGraph_t gh = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return LIGDIFF_ERR_LAUNCH;
+    int r = LIGDIFF_OK;
+    for (int i = 0; i < steps && r == LIGDIFF_OK; ++i) r = one_step();
+    const hipError_t he = hipStreamEndCapture(s, &gh);
+    if (r || he != hipSuccess || gh == nullptr) {
+      if (gh) (void)hipGraphDestroy(gh);
+      return r ? r : LIGDIFF_ERR_LAUNCH;
+    }
+    const hipError_t hi = hipGraphInstantiate(exec_out, gh, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(gh);
+    return hi == hipSuccess ? LIGDIFF_OK : LIGDIFF_ERR_LAUNCH;
+  };
+  hipGraphExec_t exec4 = nullptr, exec1 = nullptr;
+  const int groups = n_steps / kGroup, rest = n_steps % kGroup;
   rc = LIGDIFF_OK;
-  for (int i = 0; i < n_steps; ++i)
-    if (hipGraphLaunch(exec, s) != hipSuccess) { rc = LIGDIFF_ERR_LAUNCH; break; }
-  // the executable graph must outlive its queued launches
-  if (hipStreamSynchronize(s) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
-  (void)hipGraphExecDestroy(exec);
-  (void)hipGraphDestroy(graph_h);
+  if (groups > 0) rc = capture(kGroup, &exec4);
+  if (rc == LIGDIFF_OK && rest > 0) rc = capture(1, &exec1);
+  for (int i = 0; i < groups && rc == LIGDIFF_OK; ++i)
+    if (hipGraphLaunch(exec4, s) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
+  for (int i = 0; i < rest && rc == LIGDIFF_OK; ++i)
+    if (hipGraphLaunch(exec1, s) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
+  // the executable graphs must outlive their queued launches
+  if (hipStreamSynchronize(s) != hipSuccess && rc == LIGDIFF_OK) rc = LIGDIFF_ERR_LAUNCH;
+  if (exec4) (void)hipGraphExecDestroy(exec4);
+  if (exec1) (void)hipGraphExecDestroy(exec1);
   return rc;
 }
 

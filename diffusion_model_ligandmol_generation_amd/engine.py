@@ -265,7 +265,8 @@ class ScoreNetworkEngine:
         """Whole reverse loop in the library (hipGraph replay); x / pos updated in place."""
         n_steps = model.timesteps if n_steps is None else n_steps
         guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
-        nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, guided)
+        nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
+                                                              int(n_steps))
         ws = self.workspace(nbytes)
         if properties is not None:
             properties = properties.contiguous().float()

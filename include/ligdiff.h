@@ -264,19 +264,22 @@ int ligdiff_pos_step(float* pos, const float* eps_pos, const float* eps_pos_unco
                      uint32_t step, int64_t atom_offset, void* stream);
 
 /*
- * Whole 1000-step DDPM loop of generation.py:422-484 for a packed batch of molecules:
- * captures one reverse step (forward [+ unconditional forward] + fused update) into a
- * hipGraph on `stream` and replays it n_steps times.  x / pos hold the initial noise on
- * entry and the sample on return.  properties NULL -> unguided.  use_graph != 0 needs a
- * non-default stream (the legacy default stream cannot be captured) and returns after
- * the stream has drained; use_graph == 0 only enqueues.
+ * Whole 1000-step DDPM loop of generation.py:422-484 for a packed batch of molecules.  The time
+ * embedding and adaLN parameters of all n_steps timesteps are computed once up front (they depend
+ * on the step index only); reverse steps (forward [+ unconditional forward] + fused update) are
+ * captured four at a time into a hipGraph on `stream` and replayed, the step index living in
+ * device memory.  x / pos hold the initial noise on entry and the sample on return.
+ * properties NULL -> unguided.  use_graph != 0 needs a non-default stream (the legacy default
+ * stream cannot be captured) and returns after the stream has drained; use_graph == 0 only
+ * enqueues.  The workspace size depends on n_steps (the per-timestep tables).
  */
 int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
                         const float* properties, float guidance_scale, float temperature,
                         const float* betas, const float* alphas, const float* alphas_cumprod,
                         int32_t n_steps, uint64_t seed, int64_t atom_offset, int use_graph,
                         void* workspace, size_t workspace_bytes, void* stream);
-size_t ligdiff_ddpm_sample_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided);
+size_t ligdiff_ddpm_sample_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided,
+                                           int32_t n_steps);
 
 /* Fills out[n] with the N(0,1) draws the in-kernel Philox stream yields for
  * (seed, step, global element index offset..offset+n): lets a host reproduce a run. */

@@ -20,7 +20,7 @@ def make(B, offset):
     N = g.n_atoms
     x = eng.philox_normal(N * 119, 1, 0xFFFFFFFF, 0, offset * 119, 1.0).view(N, 119)
     pos = eng.philox_normal(N * 3, 1, 0xFFFFFFFF, 1, offset * 3, 1.0).view(N, 3)
-    nb = lib.ligdiff_ddpm_sample_workspace_bytes(g.n_atoms, g.n_edges, g.n_mols, 0)
+    nb = lib.ligdiff_ddpm_sample_workspace_bytes(g.n_atoms, g.n_edges, g.n_mols, 0, steps)
     ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     return g, x, pos, ws, offset, torch.cuda.Stream()
 
