@@ -325,7 +325,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     }
     if (E > 0) {
       PB("e3_%d.edge_geom", l);
-      hipLaunchKernelGGL(k_edge_geom, dim3(ceil_div(E, 256)), dim3(256), 0, s, pos_l, g->src, g->dst,
+      hipLaunchKernelGGL(k_edge_geom, dim3(ceil_div(E, 128)), dim3(256), 0, s, pos_l, g->src, g->dst,
                          w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB0_B)], w[W_E3(l, E3_RB2_W)], w[W_E3(l, E3_RB2_B)],
                          F(L.rel[l]), F(L.rbf[l]), S(L.dist[l]), S(L.r1pre[l]), E);
       PE();

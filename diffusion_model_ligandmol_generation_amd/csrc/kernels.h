@@ -49,49 +49,48 @@ __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ 
   }
 }
 
-// Edge geometry + radial MLP, model1.py:88-93, one lane per CSR edge:
+// Edge geometry + radial MLP, model1.py:88-93, 32 CSR edges per wave:
 //   rel = pos[dst] - pos[src];  d = ||rel + 1e-8||;  rbf = W2 SiLU(w0 d + b0) + b2
+// The 32 -> 32 layer is a 32x32x32 product per wave on the matrix cores
+// (16 x v_mfma_f32_32x32x2_f32): lane (i, h) owns edge i and builds the hidden units k = 2s + h
+// in registers as the A operand; the B operand is W2[n = lane & 31][2s + h].
 __global__ __launch_bounds__(256) void k_edge_geom(
     const float* __restrict__ pos, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
     const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ W2,
     const float* __restrict__ b2, float* __restrict__ rel, float* __restrict__ rbf,
     float* __restrict__ dist_out, float* __restrict__ r1pre_out, int E) {
-  __shared__ float sW2[32 * 32];
-  __shared__ float sw0[32], sb0[32], sb2[32];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 1024; i += 256) sW2[i] = W2[i];
-  if (tid < 32) { sw0[tid] = w0[tid]; sb0[tid] = b0[tid]; sb2[tid] = b2[tid]; }
-  __syncthreads();
-  const int e = blockIdx.x * 256 + tid;
-  if (e >= E) return;
-  const int s = src[e], d = dst[e];
-  const float rx = pos[(size_t)d * 3 + 0] - pos[(size_t)s * 3 + 0];
-  const float ry = pos[(size_t)d * 3 + 1] - pos[(size_t)s * 3 + 1];
-  const float rz = pos[(size_t)d * 3 + 2] - pos[(size_t)s * 3 + 2];
+  const int lane = threadIdx.x & 63, fi = lane & 31, h = lane >> 5;
+  const int e0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+  if (e0 >= E) return;
+  const int e = e0 + fi;
+  const int ec = e < E ? e : E - 1;
+  const int sa = src[ec], da = dst[ec];
+  const float rx = pos[(size_t)da * 3 + 0] - pos[(size_t)sa * 3 + 0];
+  const float ry = pos[(size_t)da * 3 + 1] - pos[(size_t)sa * 3 + 1];
+  const float rz = pos[(size_t)da * 3 + 2] - pos[(size_t)sa * 3 + 2];
   const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
   const float dist = sqrtf(ex * ex + ey * ey + ez * ez);
-  f32x4 rv = {rx, ry, rz, 0.f};
-  *reinterpret_cast<f32x4*>(rel + (size_t)e * 4) = rv;
-  if (dist_out != nullptr) dist_out[e] = dist;
-  float r1[32];
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    const float pre = dist * sw0[j] + sb0[j];
-    r1[j] = silu(pre);
-    if (r1pre_out != nullptr) r1pre_out[(size_t)e * 32 + j] = pre;
+  if (h == 0 && e < E) {
+    const f32x4 rv = {rx, ry, rz, 0.f};
+    *reinterpret_cast<f32x4*>(rel + (size_t)e * 4) = rv;
+    if (dist_out != nullptr) dist_out[e] = dist;
   }
+  f32x16 acc;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    f32x4 o;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* w2row = W2 + fi * 32 + h;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int jo = q * 4 + c;
-      float a = 0.f;
+  for (int s = 0; s < 16; ++s) {
+    const int k = 2 * s + h;
+    const float pre = dist * w0[k] + b0[k];
+    if (r1pre_out != nullptr && e < E) r1pre_out[(size_t)e * 32 + k] = pre;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(silu(pre), w2row[2 * s], acc, 0, 0, 0);
+  }
+  const float bias = b2[fi];
 #pragma unroll
-      for (int j = 0; j < 32; ++j) a += sW2[jo * 32 + j] * r1[j];
-      o[c] = a + sb2[jo];
-    }
-    *reinterpret_cast<f32x4*>(rbf + (size_t)e * 32 + q * 4) = o;
+  for (int r = 0; r < 16; ++r) {
+    const int row = e0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (row < E) rbf[(size_t)row * 32 + fi] = acc[r] + bias;
   }
 }
 
