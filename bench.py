@@ -52,12 +52,14 @@ def cpu_baseline(n_steps_cap=None):
     g = torch.Generator().manual_seed(1234)
     noise = lambda shape: torch.randn(*shape, generator=g)  # noqa: E731
     cores = torch.get_num_threads()
+    n_mols = 3
     t0 = time.time()
     with torch.no_grad():
-        oracle.ddpm_sample(sd, sched, ATOMS, noise, None, 1.0, 1.0, max_atoms=100, pad=True)
+        for _ in range(n_mols):
+            oracle.ddpm_sample(sd, sched, ATOMS, noise, None, 1.0, 1.0, max_atoms=100, pad=True)
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "molecules/s", "cores": cores, "kind": "port",
-            "sample": f"1 molecule x {ATOMS} atoms x {T_STEPS} DDPM steps, one molecule per forward padded to "
+    return {"value": n_mols / dt, "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": f"{n_mols} molecules x {ATOMS} atoms x {T_STEPS} DDPM steps, one molecule per forward padded to "
                       f"max_atoms=100 as the reference runs it ({dt:.1f} s)"}
 
 
@@ -72,9 +74,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # LIGDIFF_BENCH_REHEARSE=1: run the N > 1 code path on a box with ONE GPU (all ranks on cuda:0, gloo
+    # for the barrier and the max-reduce); the numbers of such a run mean nothing.
+    rehearse = os.environ.get("LIGDIFF_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -110,7 +120,7 @@ def main():
     fence()
     dt = time.time() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     finite = bool(torch.isfinite(x).all() and torch.isfinite(pos).all())

@@ -30,6 +30,96 @@ struct EpiNull {  // keeps the accumulators alive with one store per lane
   }
 };
 
+
+// Experimental copies of the column-split main loop with parts removed (results are garbage):
+// MODE 0 = as shipped, 1 = no DMA inside the loop, 2 = no DMA and no barriers, 3 = MFMA only.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_cs_dbg(GemmCore g, APtrPlain ap, EpiNull epi) {
+  __shared__ __attribute__((aligned(1024))) float smem3[G3_LDS_BYTES / 4];
+  constexpr int A_FL = 128 * G2_ROWF;
+  constexpr int ST = G3_STAGE_FLOATS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slab = wave & 3, half = wave >> 2;
+  const int by = blockIdx.y;
+  const int row_blk = blockIdx.x * 128;
+  const float* __restrict__ W = g.W[by];
+  f32x16 acc[4];
+  for (int ct = 0; ct < 4; ++ct)
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+  const int pr = lane >> 2, ps = lane & 3;
+  const int lslot = ps ^ ((pr >> 2) & 3);
+  int a_row = row_blk + wave * 16 + pr;
+  a_row = a_row < g.M ? a_row : g.M - 1;
+  const float* w_src[2];
+  for (int i = 0; i < 2; ++i) {
+    int n = (wave * 2 + i) * 16 + pr;
+    n = n < g.n_valid ? n : g.n_valid - 1;
+    w_src[i] = W + (size_t)n * g.ldw + lslot * 4;
+  }
+  auto issue = [&](int kc, int buf) {
+    float* sA = smem3 + buf * ST;
+    float* sW = sA + A_FL;
+    const int k0 = kc * G2_BK;
+    lds_dma16(ap.ptr(a_row, k0 + lslot * 4), sA + wave * 256);
+    for (int i = 0; i < 2; ++i) lds_dma16(w_src[i] + k0, sW + (wave * 2 + i) * 256);
+  };
+  const int nk = g.K / G2_BK;
+  const int fi = lane & 31, hk = lane >> 5;
+  const int swz = (fi >> 2) & 3;
+  const int off0 = ((0 * 2 + hk) ^ swz) * 4, off1 = ((1 * 2 + hk) ^ swz) * 4;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  int cur = 0;
+  f32x4 a0, a1, b[2][2];
+  {
+    const float* sA = smem3;
+    const float* sW = sA + A_FL + (half * 128 + fi) * G2_ROWF;
+    const float* arow = sA + (slab * 32 + fi) * G2_ROWF;
+    a0 = *reinterpret_cast<const f32x4*>(arow + off0); a1 = *reinterpret_cast<const f32x4*>(arow + off1);
+    b[0][0] = *reinterpret_cast<const f32x4*>(sW + off0); b[0][1] = *reinterpret_cast<const f32x4*>(sW + off1);
+    b[1][0] = b[0][1]; b[1][1] = b[0][0];
+  }
+  for (int kc = 0; kc < nk; ++kc) {
+    if (MODE <= 1) {
+      if (MODE == 0) { if (kc + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F73); else __builtin_amdgcn_s_waitcnt(0x0F70); }
+      __builtin_amdgcn_s_barrier();
+    }
+    if (MODE == 0 && kc + 2 < nk) issue(kc + 2, cur == 0 ? 2 : cur - 1);
+    const float* sA = smem3 + cur * ST;
+    const float* sW = sA + A_FL + (half * 128 + fi) * G2_ROWF;
+    const float* arow = sA + (slab * 32 + fi) * G2_ROWF;
+    if (MODE <= 2) {
+      a0 = *reinterpret_cast<const f32x4*>(arow + off0);
+      a1 = *reinterpret_cast<const f32x4*>(arow + off1);
+      b[0][0] = *reinterpret_cast<const f32x4*>(sW + off0);
+      b[0][1] = *reinterpret_cast<const f32x4*>(sW + off1);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[ct & 1][0][j], acc[ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE <= 2 && ct + 1 < 4) {
+        b[(ct + 1) & 1][0] = *reinterpret_cast<const f32x4*>(sW + (ct + 1) * 32 * G2_ROWF + off0);
+        b[(ct + 1) & 1][1] = *reinterpret_cast<const f32x4*>(sW + (ct + 1) * 32 * G2_ROWF + off1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[ct & 1][1][j], acc[ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  HalfMailbox mb{smem3 + 3 * ST, wave, lane};
+  epi.cs(acc, row_blk + slab * 32, by, half, lane, mb);
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <class F>
@@ -171,6 +261,24 @@ int main() {
       ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiNull>), dim3(232, 1), dim3(512), 0, 0, g2, ap, en); }, 20);
       report("cs           M29696 K256 N256 no epilogue", ms, 2.0 * M * 256 * 256);
     }
+  }
+  printf("--- main-loop ablation (ffn_up shape, by=4; and ffn_down shape K=1024 by=1)\n");
+  {
+    EpiNull en{C};
+    GemmCore g = core(M, 256, 4, 256);
+    APtrPlain ap{A, 256};
+    GemmCore gd = core(M, 1024, 1, 1024);
+    APtrPlain apd{A, 1024};
+    float ms;
+#define RUN_DBG(MODE, name)                                                                                                   \
+    ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_dbg<MODE>), dim3(232, 4), dim3(512), 0, 0, g, ap, en); }, 20);             \
+    report(name " by=4 K=256", ms, 2.0 * M * 256 * 1024);                                                                     \
+    ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_dbg<MODE>), dim3(232, 1), dim3(512), 0, 0, gd, apd, en); }, 20);           \
+    report(name " by=1 K=1024", ms, 2.0 * M * 1024 * 256);
+    RUN_DBG(0, "dbg0 full")
+    RUN_DBG(1, "dbg1 no DMA in loop")
+    RUN_DBG(2, "dbg2 no DMA, no barrier")
+    RUN_DBG(3, "dbg3 MFMA only")
   }
   printf("--- cold operands: rotating over 6 buffer sets (A, resid, C each 30 MB; W 6 copies)\n");
   {
