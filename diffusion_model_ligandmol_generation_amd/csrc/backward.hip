@@ -8,6 +8,8 @@
 
 #include "forward.h"
 #include "gemm_bwd.h"
+#include "gemm_dw.h"
+#include "launch.h"
 #include "kernels_bwd.h"
 #include "weights.h"
 
@@ -15,6 +17,7 @@ struct BwdLayout {
   size_t dxa, n256b, n256c, n256d, n512, n768, n1024, G;
   size_t e256a, e256b, e256c, e128, e32a, e32b, e32c, e4;
   size_t dmod[3], b256a, b256b, b256c, b256d, b512, b2048, b8, bhid;
+  size_t wt;   // transposed weight block of the dX GEMM in flight (<= 1024 x 256 floats)
   size_t total;
 };
 static void bwd_layout(BwdLayout* L, int64_t N, int64_t E, int32_t B) {
@@ -28,6 +31,7 @@ static void bwd_layout(BwdLayout* L, int64_t N, int64_t E, int32_t B) {
   L->b256a = take((size_t)B * 256); L->b256b = take((size_t)B * 256); L->b256c = take((size_t)B * 256);
   L->b256d = take((size_t)B * 256); L->b512 = take((size_t)B * 512); L->b2048 = take((size_t)B * 2048);
   L->b8 = take((size_t)B * 8); L->bhid = take((size_t)B * 512);
+  L->wt = take(1024 * 256);
   L->total = off;
 }
 
@@ -37,11 +41,39 @@ extern "C" size_t ligdiff_backward_workspace_bytes(int64_t n_atoms, int64_t n_ed
   return L.total;
 }
 
+// dst[c, r] = src[r, c] for a [rows, cols] block with leading dimension ld (32 x 32 tiles through LDS)
+__global__ __launch_bounds__(256) void k_transpose_block(const float* __restrict__ src, int rows, int cols, int ld,
+                                                         float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(size_t)(r0 + i) * ld + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < cols && r0 + tx < rows) dst[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+// Scratch for the transposed weight block (set per ligdiff_backward call from its workspace).
+static thread_local float* g_wt_scratch = nullptr;
+
 // C[M, ncols] (+)= dY[M, K] * W[K, ncols]  [* act'(pre)]     (W is the forward weight [out=K, in])
+// When the shape allows (ncols a multiple of 256, K of 16, aligned rows) the weight block is
+// transposed into scratch - a few hundred KB - and the product runs on the forward pass's LDS-DMA
+// kernel, whose operands both need the reduction index contiguous.
 template <int NT, int MUL, bool ACCUM>
 static void gemm_dx(const float* dY, int lddy, int M, int K, const float* W, int ldw, int ncols, float* C, int ldc,
                     const float* pre, int ldp, hipStream_t s) {
   if (M <= 0) return;
+  if (NT == 8 && use_cs() && g_wt_scratch != nullptr && ncols % 256 == 0 && K % G2_BK == 0 && lddy % 4 == 0 &&
+      ncols / 256 <= 8 && (size_t)K * ncols <= 1024 * 256) {
+    hipLaunchKernelGGL(k_transpose_block, dim3(ceil_div(ncols, 32), ceil_div(K, 32)), dim3(256), 0, s, W, K, ncols, ldw,
+                       g_wt_scratch);
+    GemmCore g = core_blocks(M, K, 256, g_wt_scratch, K, ncols / 256, 256);
+    EpiBwdStore<8, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f};
+    launch_gemm_cs(g, APtrPlain{dY, lddy}, e, ncols / 256, s);
+    return;
+  }
   OpRow a{dY, lddy, M, K};
   OpK b{W, ldw, ncols, K};
   EpiBwdStore<NT, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f};
@@ -51,10 +83,27 @@ static void gemm_dx(const float* dY, int lddy, int M, int K, const float* W, int
 }
 
 // dW[nout, kin] += dY[rows, nout]^T * X[rows, kin]   (split over rows, float atomics)
+// db (nullable, LDS-DMA path only - see the return value): bias gradient sum_rows dY, from the same pass.
+// Returns true when db was produced here (the caller then skips its separate column-sum launch).
 template <int NT>
-static void gemm_dw(const float* dY, int lddy, int nout, const float* X, int ldx, int kin, int rows, float* dW,
-                    int lddw, hipStream_t s) {
-  if (rows <= 0) return;
+static bool gemm_dw(const float* dY, int lddy, int nout, const float* X, int ldx, int kin, int rows, float* dW,
+                    int lddw, hipStream_t s, float* db = nullptr) {
+  if (rows <= 0) return false;
+  if (use_cs() && kin % 256 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && nout % 4 == 0 && nout >= 4) {
+    const int bx = ceil_div(nout, 128), by = kin / 256;
+    // every slice of the row range adds a full 128 x 256 tile with atomics, so the slice count is kept
+    // near 1.5 workgroups per CU (measured best of 128 / 256 / 384 / 512 on the training step)
+    static const int target_blocks = getenv("LIGDIFF_DW_BLOCKS") ? atoi(getenv("LIGDIFF_DW_BLOCKS")) : 384;
+    int splits = ceil_div(target_blocks, bx * by);
+    const int max_splits = ceil_div(rows, 64);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int m_split = (int)align_up(ceil_div(rows, splits), 16);
+    splits = ceil_div(rows, m_split);
+    GemmDwArgs a{dY, lddy, nout, X, ldx, kin, rows, m_split, dW, lddw, db};
+    hipLaunchKernelGGL(gemm_dw_kernel, dim3(bx, by, splits), dim3(512), 0, s, a);
+    return db != nullptr;
+  }
   OpK a{dY, lddy, nout, rows};
   OpK b{X, ldx, kin, rows};
   EpiBwdAtomic<NT> e{nout, kin, dW, lddw};
@@ -67,6 +116,7 @@ static void gemm_dw(const float* dY, int lddy, int nout, const float* X, int ldx
   splits = ceil_div(rows, k_split);
   dim3 grid(bx, by, splits);
   hipLaunchKernelGGL((gemm_bwd_kernel<NT, OpK, OpK, EpiBwdAtomic<NT>>), grid, dim3(256), 0, s, a, b, k_split, e);
+  return false;
 }
 
 static void colsum(const float* Y, int ld, int M, int ncols, const float* rowscale, float* out, hipStream_t s) {
@@ -111,21 +161,22 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
   auto T = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };         // backward scratch
   const int nb4N = ceil_div(N, 4), nb4B = ceil_div(B, 4);
   float* dxa = T(L.dxa);
+  g_wt_scratch = T(L.wt);
 
   // ------------------------------------------------------------------ heads (model1.py:741-746)
   const float* x_last = A(F.x2[2]);
   float* dyh = T(L.n512);
   gemm_dx<8, MUL_NONE, false>(d_atom, LD_A, N, LD_A, w[W_HEAD(0, HEAD_W3)], 256, 256, dyh, 512, nullptr, 0, s);
   hipLaunchKernelGGL(k_small_dx<3>, dim3(nb4N), dim3(256), 0, s, d_pos, w[W_HEAD(1, HEAD_W3)], dyh, 512, 256, N);
-  gemm_dw<8>(d_atom, LD_A, LD_A, A(F.yh), 512, 256, N, gr[W_HEAD(0, HEAD_W3)], 256, s);
-  colsum(d_atom, LD_A, N, LD_A, nullptr, gr[W_HEAD(0, HEAD_B3)], s);
+  if (!gemm_dw<8>(d_atom, LD_A, LD_A, A(F.yh), 512, 256, N, gr[W_HEAD(0, HEAD_W3)], 256, s, gr[W_HEAD(0, HEAD_B3)]))
+    colsum(d_atom, LD_A, N, LD_A, nullptr, gr[W_HEAD(0, HEAD_B3)], s);
   hipLaunchKernelGGL(k_small_dw<3>, dim3(ceil_div(N, 128)), dim3(256), 0, s, d_pos, A(F.yh), 512, 256,
                      gr[W_HEAD(1, HEAD_W3)], gr[W_HEAD(1, HEAD_B3)], N);
   for (int h = 0; h < 2; ++h) {
     ln_bwd<1, 0>(A(F.u_head) + h * 256, 512, w[W_HEAD(h, HEAD_G)], w[W_HEAD(h, HEAD_BE)], 1e-5f, dyh + h * 256, 512,
                  nullptr, 0, nullptr, dyh + h * 256, 512, gr[W_HEAD(h, HEAD_G)], gr[W_HEAD(h, HEAD_BE)], N, s);
-    gemm_dw<8>(dyh + h * 256, 512, 256, x_last, 256, 256, N, gr[W_HEAD(h, HEAD_W0)], 256, s);
-    colsum(dyh + h * 256, 512, N, 256, nullptr, gr[W_HEAD(h, HEAD_B0)], s);
+    if (!gemm_dw<8>(dyh + h * 256, 512, 256, x_last, 256, 256, N, gr[W_HEAD(h, HEAD_W0)], 256, s, gr[W_HEAD(h, HEAD_B0)]))
+      colsum(dyh + h * 256, 512, N, 256, nullptr, gr[W_HEAD(h, HEAD_B0)], s);
   }
   gemm_dx<8, MUL_NONE, false>(dyh, 512, N, 256, w[W_HEAD(0, HEAD_W0)], 256, 256, dxa, 256, nullptr, 0, s);
   gemm_dx<8, MUL_NONE, true>(dyh + 256, 512, N, 256, w[W_HEAD(1, HEAD_W0)], 256, 256, dxa, 256, nullptr, 0, s);
@@ -136,8 +187,8 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
                        gr[W_HEAD(2, HEAD_W3)], gr[W_HEAD(2, HEAD_B3)], B);
     ln_bwd<1, 0>(A(F.u_ph), 256, w[W_HEAD(2, HEAD_G)], w[W_HEAD(2, HEAD_BE)], 1e-5f, dph, 256, nullptr, 0, nullptr, dph,
                  256, gr[W_HEAD(2, HEAD_G)], gr[W_HEAD(2, HEAD_BE)], B, s);
-    gemm_dw<8>(dph, 256, 256, A(F.pooled), 256, 256, B, gr[W_HEAD(2, HEAD_W0)], 256, s);
-    colsum(dph, 256, B, 256, nullptr, gr[W_HEAD(2, HEAD_B0)], s);
+    if (!gemm_dw<8>(dph, 256, 256, A(F.pooled), 256, 256, B, gr[W_HEAD(2, HEAD_W0)], 256, s, gr[W_HEAD(2, HEAD_B0)]))
+      colsum(dph, 256, B, 256, nullptr, gr[W_HEAD(2, HEAD_B0)], s);
     float* dpool = T(L.b256b);
     gemm_dx<8, MUL_NONE, false>(dph, 256, B, 256, w[W_HEAD(2, HEAD_W0)], 256, 256, dpool, 256, nullptr, 0, s);
     hipLaunchKernelGGL(k_pool_bwd, dim3(nb4N), dim3(256), 0, s, dpool, g->mol_ptr, g->atom_mol, dxa, N);
@@ -155,20 +206,20 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
     float* t256c = T(L.n256c);
     // x2 = x1 + gate_mlp * (ffh W3^T + b)
     hipLaunchKernelGGL(k_gate_bwd, dim3(nb4B), dim3(256), 0, s, dxa, A(F.fproj[l]), mod, 1536, 1280, g->mol_ptr, B, t256b, dmod);
-    gemm_dw<8>(t256b, 256, 256, A(F.ffh[l]), 1024, 1024, N, gr[W_DIT(l, DIT_FF3_W)], 1024, s);
-    colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_FF3_B)], s);
+    if (!gemm_dw<8>(t256b, 256, 256, A(F.ffh[l]), 1024, 1024, N, gr[W_DIT(l, DIT_FF3_W)], 1024, s, gr[W_DIT(l, DIT_FF3_B)]))
+      colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_FF3_B)], s);
     float* dffh = T(L.n1024);
     gemm_dx<8, MUL_GELU_GRAD, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1024, dffh, 1024,
                                      A(F.ffh_pre[l]), 1024, s);
-    gemm_dw<8>(dffh, 1024, 1024, A(F.xn2[l]), 256, 256, N, gr[W_DIT(l, DIT_FF0_W)], 256, s);
-    colsum(dffh, 1024, N, 1024, nullptr, gr[W_DIT(l, DIT_FF0_B)], s);
+    if (!gemm_dw<8>(dffh, 1024, 1024, A(F.xn2[l]), 256, 256, N, gr[W_DIT(l, DIT_FF0_W)], 256, s, gr[W_DIT(l, DIT_FF0_B)]))
+      colsum(dffh, 1024, N, 1024, nullptr, gr[W_DIT(l, DIT_FF0_B)], s);
     gemm_dx<8, MUL_NONE, false>(dffh, 1024, N, 1024, w[W_DIT(l, DIT_FF0_W)], 256, 256, t256c, 256, nullptr, 0, s);
     hipLaunchKernelGGL(k_lnmod_bwd, dim3(nb4B), dim3(256), 0, s, A(F.x1[l]), t256c, dxa, mod, 1536, 768, 1024,
                        g->mol_ptr, B, dxa, dmod);
     // x1 = x_in + gate_msa * (att Wo^T + b)
     hipLaunchKernelGGL(k_gate_bwd, dim3(nb4B), dim3(256), 0, s, dxa, A(F.oproj[l]), mod, 1536, 512, g->mol_ptr, B, t256b, dmod);
-    gemm_dw<8>(t256b, 256, 256, A(F.att[l]), 256, 256, N, gr[W_DIT(l, DIT_OUT_W)], 256, s);
-    colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_OUT_B)], s);
+    if (!gemm_dw<8>(t256b, 256, 256, A(F.att[l]), 256, 256, N, gr[W_DIT(l, DIT_OUT_W)], 256, s, gr[W_DIT(l, DIT_OUT_B)]))
+      colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_OUT_B)], s);
     gemm_dx<8, MUL_NONE, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_OUT_W)], 256, 256, t256c, 256, nullptr, 0, s);
     float* dqkv = T(L.n768);
     if (g->max_mol_atoms <= 64) {
@@ -178,8 +229,8 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
       hipLaunchKernelGGL(k_attention_bwd, dim3(B * 4), dim3(128), att_lds_hpb4 / 2, s, A(F.qkv[l]), A(F.att[l]), t256c,
                          A(F.lse[l]), g->mol_ptr, dqkv, 128);
     }
-    gemm_dw<8>(dqkv, 768, 768, A(F.xn1[l]), 256, 256, N, gr[W_DIT(l, DIT_INP_W)], 256, s);
-    colsum(dqkv, 768, N, 768, nullptr, gr[W_DIT(l, DIT_INP_B)], s);
+    if (!gemm_dw<8>(dqkv, 768, 768, A(F.xn1[l]), 256, 256, N, gr[W_DIT(l, DIT_INP_W)], 256, s, gr[W_DIT(l, DIT_INP_B)]))
+      colsum(dqkv, 768, N, 768, nullptr, gr[W_DIT(l, DIT_INP_B)], s);
     gemm_dx<8, MUL_NONE, false>(dqkv, 768, N, 768, w[W_DIT(l, DIT_INP_W)], 256, 256, t256c, 256, nullptr, 0, s);
     hipLaunchKernelGGL(k_lnmod_bwd, dim3(nb4B), dim3(256), 0, s, x_in, t256c, dxa, mod, 1536, 0, 256, g->mol_ptr, B,
                        dxa, dmod);
@@ -196,13 +247,13 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
     // h_out = h_in + LN(hid Wn2^T + b)
     ln_bwd<0, 0>(A(F.u_h[l]), 256, w[W_E3(l, E3_NN3_G)], w[W_E3(l, E3_NN3_B)], 1e-5f, dxa, 256, nullptr, 0, nullptr,
                  t256b, 256, gr[W_E3(l, E3_NN3_G)], gr[W_E3(l, E3_NN3_B)], N, s);
-    gemm_dw<8>(t256b, 256, 256, A(F.hid[l]), 256, 256, N, gr[W_E3(l, E3_NN2_W)], 256, s);
-    colsum(t256b, 256, N, 256, nullptr, gr[W_E3(l, E3_NN2_B)], s);
+    if (!gemm_dw<8>(t256b, 256, 256, A(F.hid[l]), 256, 256, N, gr[W_E3(l, E3_NN2_W)], 256, s, gr[W_E3(l, E3_NN2_B)]))
+      colsum(t256b, 256, N, 256, nullptr, gr[W_E3(l, E3_NN2_B)], s);
     gemm_dx<8, MUL_SILU_GRAD, false>(t256b, 256, N, 256, w[W_E3(l, E3_NN2_W)], 256, 256, t256c, 256, A(F.hid_pre[l]),
                                      256, s);
     gemm_dw<8>(t256c, 256, 256, h_in, 256, 256, N, gr[W_E3(l, E3_NN0_W)], 512, s);
-    gemm_dw<8>(t256c, 256, 256, A(F.agg[l]), 256, 256, N, gr[W_E3(l, E3_NN0_W)] + 256, 512, s);
-    colsum(t256c, 256, N, 256, nullptr, gr[W_E3(l, E3_NN0_B)], s);
+    if (!gemm_dw<8>(t256c, 256, 256, A(F.agg[l]), 256, 256, N, gr[W_E3(l, E3_NN0_W)] + 256, 512, s, gr[W_E3(l, E3_NN0_B)]))
+      colsum(t256c, 256, N, 256, nullptr, gr[W_E3(l, E3_NN0_B)], s);
     gemm_dx<8, MUL_NONE, true>(t256c, 256, N, 256, w[W_E3(l, E3_NN0_W)], 512, 256, dxa, 256, nullptr, 0, s);
     gemm_dx<8, MUL_NONE, false>(t256c, 256, N, 256, w[W_E3(l, E3_NN0_W)] + 256, 512, 256, dagg, 256, nullptr, 0, s);
     if (E > 0) {
@@ -214,14 +265,14 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
       // coordinate gate
       hipLaunchKernelGGL(k_coord_bwd, dim3(1024), dim3(256), 0, s, G, g->src, g->dst, A(F.rel[l]), A(F.cw[l]),
                          A(F.hc_pre[l]), w[W_E3(l, E3_CN2_W)], drel, dhc, gr[W_E3(l, E3_CN2_W)], gr[W_E3(l, E3_CN2_B)], E);
-      gemm_dw<8>(dhc, 128, 128, A(F.msg[l]), 256, 256, E, gr[W_E3(l, E3_CN0_W)], 256, s);
-      colsum(dhc, 128, E, 128, nullptr, gr[W_E3(l, E3_CN0_B)], s);
+      if (!gemm_dw<8>(dhc, 128, 128, A(F.msg[l]), 256, 256, E, gr[W_E3(l, E3_CN0_W)], 256, s, gr[W_E3(l, E3_CN0_B)]))
+        colsum(dhc, 128, E, 128, nullptr, gr[W_E3(l, E3_CN0_B)], s);
       gemm_dx<8, MUL_NONE, false>(dhc, 128, E, 128, w[W_E3(l, E3_CN0_W)], 256, 256, e256a, 256, nullptr, 0, s);
       // msg = LN(a1 W2^T + b); its gradient = coordinate branch + aggregated branch (dagg[dst])
       ln_bwd<0, 0>(A(F.u_m[l]), 256, w[W_E3(l, E3_EN3_G)], w[W_E3(l, E3_EN3_B)], 1e-5f, e256a, 256, dagg, 256, g->dst,
                    e256b, 256, gr[W_E3(l, E3_EN3_G)], gr[W_E3(l, E3_EN3_B)], E, s);
-      gemm_dw<8>(e256b, 256, 256, A(F.a1[l]), 256, 256, E, gr[W_E3(l, E3_EN2_W)], 256, s);
-      colsum(e256b, 256, E, 256, nullptr, gr[W_E3(l, E3_EN2_B)], s);
+      if (!gemm_dw<8>(e256b, 256, 256, A(F.a1[l]), 256, 256, E, gr[W_E3(l, E3_EN2_W)], 256, s, gr[W_E3(l, E3_EN2_B)]))
+        colsum(e256b, 256, E, 256, nullptr, gr[W_E3(l, E3_EN2_B)], s);
       gemm_dx<8, MUL_SILU_GRAD, false>(e256b, 256, E, 256, w[W_E3(l, E3_EN2_W)], 256, 256, dpre, 256, A(F.pre_e[l]),
                                        256, s);
       // pre = Pa[src] + Pb[dst] + Wc rbf + b1
@@ -233,8 +284,8 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
       float* r1 = T(L.e32c);
       hipLaunchKernelGGL(k_radial_bwd, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, A(F.r1pre[l]), A(F.dist[l]),
                          A(F.rel[l]), w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB2_W)], drel, dr1pre, r1, E);
-      gemm_dw<4>(drbf, 32, 32, r1, 32, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s);
-      colsum(drbf, 32, E, 32, nullptr, gr[W_E3(l, E3_RB2_B)], s);
+      if (!gemm_dw<4>(drbf, 32, 32, r1, 32, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s, gr[W_E3(l, E3_RB2_B)]))
+        colsum(drbf, 32, E, 32, nullptr, gr[W_E3(l, E3_RB2_B)], s);
       colsum(dr1pre, 32, E, 32, A(F.dist[l]), gr[W_E3(l, E3_RB0_W)], s);
       colsum(dr1pre, 32, E, 32, nullptr, gr[W_E3(l, E3_RB0_B)], s);
       float* dP = T(L.n512);
@@ -253,8 +304,8 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
     float* du = T(L.n256b);
     ln_bwd<0, 1>(A(F.ua), 256, w[W_ATOM_G], w[W_ATOM_BE], 1e-5f, dxa, 256, nullptr, 0, nullptr, du, 256, gr[W_ATOM_G],
                  gr[W_ATOM_BE], N, s);
-    gemm_dw<4>(du, 256, 256, x, LD_A, LD_A, N, gr[W_ATOM_W], LD_A, s);
-    colsum(du, 256, N, 256, nullptr, gr[W_ATOM_B], s);
+    if (!gemm_dw<4>(du, 256, 256, x, LD_A, LD_A, N, gr[W_ATOM_W], LD_A, s, gr[W_ATOM_B]))
+      colsum(du, 256, N, 256, nullptr, gr[W_ATOM_B], s);
     float* up = T(L.n256c);
     float* dup = T(L.n256d);
     hipLaunchKernelGGL(k_pos_embed_pre, dim3(nb4N), dim3(256), 0, s, pos, w[W_POS_W], w[W_POS_B], up, N);
@@ -279,14 +330,14 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
       hipLaunchKernelGGL(k_pilot_combine_bwd, dim3(B), dim3(256), 0, s, dmolsum, A(F.pstack), A(F.pz), A(F.pw), dstk, dz);
       hipLaunchKernelGGL(k_pilot_dw2, dim3(ceil_div(B, 64)), dim3(256), 0, s, dz, A(F.pg), B, gr[W_PAR2_W], gr[W_PAR2_B]);
       hipLaunchKernelGGL(k_pilot_dg, dim3(B), dim3(256), 0, s, dz, w[W_PAR2_W], A(F.pg_pre), dgpre);
-      gemm_dw<8>(dgpre, 256, 256, A(F.pstack), 2048, 2048, B, gr[W_PAR0_W], 2048, s);
-      colsum(dgpre, 256, B, 256, nullptr, gr[W_PAR0_B], s);
+      if (!gemm_dw<8>(dgpre, 256, 256, A(F.pstack), 2048, 2048, B, gr[W_PAR0_W], 2048, s, gr[W_PAR0_B]))
+        colsum(dgpre, 256, B, 256, nullptr, gr[W_PAR0_B], s);
       gemm_dx<8, MUL_NONE, true>(dgpre, 256, B, 256, w[W_PAR0_W], 2048, 2048, dstk, 2048, nullptr, 0, s);
       hipLaunchKernelGGL(k_gelu_elem, dim3(ceil_div((int64_t)B * 512, 256)), dim3(256), 0, s, A(F.pen_pre), hid, (int64_t)B * 512);
       PilotEncGrads pg;
       for (int e = 0; e < 8; ++e) {
-        gemm_dw<4>(dstk + e * 256, 2048, 256, hid + e * 64, 512, 64, B, gr[W_PENC(e, 2)], 64, s);
-        colsum(dstk + e * 256, 2048, B, 256, nullptr, gr[W_PENC(e, 3)], s);
+        if (!gemm_dw<4>(dstk + e * 256, 2048, 256, hid + e * 64, 512, 64, B, gr[W_PENC(e, 2)], 64, s, gr[W_PENC(e, 3)]))
+          colsum(dstk + e * 256, 2048, B, 256, nullptr, gr[W_PENC(e, 3)], s);
         pg.W2[e] = w[W_PENC(e, 2)]; pg.dw0[e] = gr[W_PENC(e, 0)]; pg.db0[e] = gr[W_PENC(e, 1)];
       }
       hipLaunchKernelGGL(k_pilot_enc_bwd, dim3(B, 8), dim3(64), 0, s, dstk, A(F.pen_pre), properties, pg);
@@ -302,17 +353,17 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
         gemm_dx<8, MUL_NONE, false>(dmod, 1536, B, 1536, w[W_DIT(l, DIT_ADA_W)], 256, 256, dstemb, 256, nullptr, 0, s);
       else
         gemm_dx<8, MUL_NONE, true>(dmod, 1536, B, 1536, w[W_DIT(l, DIT_ADA_W)], 256, 256, dstemb, 256, nullptr, 0, s);
-      gemm_dw<8>(dmod, 1536, 1536, A(F.stemb), 256, 256, B, gr[W_DIT(l, DIT_ADA_W)], 256, s);
-      colsum(dmod, 1536, B, 1536, nullptr, gr[W_DIT(l, DIT_ADA_B)], s);
+      if (!gemm_dw<8>(dmod, 1536, 1536, A(F.stemb), 256, 256, B, gr[W_DIT(l, DIT_ADA_W)], 256, s, gr[W_DIT(l, DIT_ADA_B)]))
+        colsum(dmod, 1536, B, 1536, nullptr, gr[W_DIT(l, DIT_ADA_B)], s);
     }
     float* dtemb = T(L.b256c);
     hipLaunchKernelGGL(k_time_bwd_elem, dim3(ceil_div(B * 256, 256)), dim3(256), 0, s, dmolsum, dstemb, A(F.temb), dtemb, B * 256);
-    gemm_dw<8>(dtemb, 256, 256, A(F.t1), 512, 512, B, gr[W_T2_W], 512, s);
-    colsum(dtemb, 256, B, 256, nullptr, gr[W_T2_B], s);
+    if (!gemm_dw<8>(dtemb, 256, 256, A(F.t1), 512, 512, B, gr[W_T2_W], 512, s, gr[W_T2_B]))
+      colsum(dtemb, 256, B, 256, nullptr, gr[W_T2_B], s);
     float* dt1 = T(L.b512);
     gemm_dx<8, MUL_GELU_GRAD, false>(dtemb, 256, B, 256, w[W_T2_W], 512, 512, dt1, 512, A(F.t1_pre), 512, s);
-    gemm_dw<8>(dt1, 512, 512, A(F.tf), 256, 256, B, gr[W_T0_W], 256, s);
-    colsum(dt1, 512, B, 512, nullptr, gr[W_T0_B], s);
+    if (!gemm_dw<8>(dt1, 512, 512, A(F.tf), 256, 256, B, gr[W_T0_W], 256, s, gr[W_T0_B]))
+      colsum(dt1, 512, B, 512, nullptr, gr[W_T0_B], s);
   }
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;

@@ -187,6 +187,37 @@ struct EpiBwdStore {
       }
     }
   }
+  // Column-split form (gemm3.h; N a multiple of 256): the values to accumulate into and the saved
+  // pre-activations are loaded in one batch before the first store.
+  template <class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
+    const int cb = by * 256 + half * 128 + (lane & 31);
+    float old[ACCUM ? 4 : 1][16], pv[MUL != MUL_NONE ? 4 : 1][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      const int rr = row < M ? row : M - 1;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        if (ACCUM) old[ct][r] = C[(size_t)rr * ldc + cb + ct * 32];
+        if (MUL != MUL_NONE) pv[ct][r] = pre[(size_t)rr * ldp + cb + ct * 32];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + G_ROW(r, lane);
+      if (row < M) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          float v = acc[ct][r] * alpha;
+          if (MUL == MUL_SILU_GRAD) v *= silu_grad(pv[ct][r]);
+          if (MUL == MUL_GELU_GRAD) v *= gelu_exact_grad(pv[ct][r]);
+          if (ACCUM) v += old[ct][r];
+          C[(size_t)row * ldc + cb + ct * 32] = v;
+        }
+      }
+    }
+  }
 };
 
 // C[row, col] += acc with float atomics (split reductions; C zeroed by the caller).
