@@ -54,7 +54,14 @@ class ScoreNetworkFunction(torch.autograd.Function):
         d_atom = torch.zeros(N, 119, device=dev) if d_atom is None else d_atom.contiguous().float()
         d_pos = torch.zeros(N, 3, device=dev) if d_pos is None else d_pos.contiguous().float()
         d_prop = None if d_prop is None else d_prop.contiguous().float()
-        grads = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
+        # one zero-filled buffer, carved into per-parameter views (one fill instead of ~150)
+        sizes = [int(torch.Size(s).numel()) for s in ctx.param_shapes]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 63) // 64 * 64        # 256-B aligned views
+        flat = torch.zeros(tot, dtype=torch.float32, device=dev)
+        grads = [flat[o:o + n].view(s) for o, n, s in zip(offs, sizes, ctx.param_shapes)]
         table = (C.c_void_p * len(eng.names))()
         gi = 0
         for i, name in enumerate(eng.names):
