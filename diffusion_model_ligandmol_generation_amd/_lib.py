@@ -80,6 +80,9 @@ SIGNATURES = {
                                       C.c_size_t, C.c_void_p]),
     "ligdiff_pos_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p]),
+    "ligdiff_ddim_sample": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                      C.c_void_p]),
     "ligdiff_ddpm_sample_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int, C.c_int32]),
     "ligdiff_ddpm_sample": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -271,19 +271,77 @@ __global__ __launch_bounds__(256) void k_time_gather(const int32_t* counter, Tim
 }
 // counter[1] = index of the step now in progress (read by its update kernel), counter[0] = the next
 // one.  A launch of its own, after the gather: every block of the gather reads counter[0].
-__global__ void k_advance(int32_t* counter) {
+__global__ void k_advance(int32_t* counter, int delta) {
   const int t = counter[0];
   counter[1] = t;
-  counter[0] = t - 1;
+  counter[0] = t + delta;
+}
+__global__ void k_int_to_float(const int32_t* in, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
 }
 
-extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
-                                   const float* properties, float guidance_scale, float temperature,
-                                   const float* betas, const float* alphas, const float* alphas_cumprod,
-                                   int32_t n_steps, uint64_t seed, int64_t atom_offset, int use_graph,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
-  if (!weights || !graph || !x || !pos || !betas || !alphas || !alphas_cumprod || !workspace || n_steps <= 0)
-    return LIGDIFF_ERR_ARG;
+// DDIM update (generation.py:359-381) for loop position i = *pos_dev of the timestep list ts[n_steps]:
+// t_cur = ts[i], t_next = ts[i+1] (none after the last).  One thread per element.
+__global__ __launch_bounds__(256) void k_reverse_step_ddim_list(ligdiff_step_args a, const int32_t* __restrict__ ts,
+                                                                int n_steps, const int32_t* __restrict__ pos_dev) {
+  const int64_t nx = a.n_atoms * LD_A, np = a.n_atoms * 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nx + np) return;
+  const int step = *pos_dev;
+  const int t_cur = ts[step];
+  const int t_next = step + 1 < n_steps ? ts[step + 1] : -1;
+  const bool is_pos = i >= nx;
+  const int64_t j = is_pos ? i - nx : i;
+  float* state = is_pos ? a.pos : a.x;
+  const float* ec = is_pos ? a.eps_pos : a.eps_x;
+  const float* eu = is_pos ? a.eps_pos_uncond : a.eps_x_uncond;
+  float eps = ec[j];
+  if (eu != nullptr) {
+    const float u = eu[j];
+    eps = u + a.guidance_scale * (eps - u);
+  }
+  const float at = a.alphas_cumprod[t_cur];
+  const float x0 = (state[j] - sqrtf(1.0f - at) * eps) / sqrtf(at);
+  float out = x0;
+  if (t_next >= 0) {
+    const float an = a.alphas_cumprod[t_next];
+    out = sqrtf(an) * x0 + sqrtf(1.0f - an) * eps;
+  }
+  state[j] = out;
+}
+
+// Per-step prediction gate of the DDIM loop on the guidance-combined prediction
+// (generation.py:351, :442-443, :518-541).
+__global__ void k_prediction_gate_guided(ligdiff_step_args a, const int32_t* __restrict__ atom_mol,
+                                         int32_t* __restrict__ reject) {
+  const int64_t nx = a.n_atoms * LD_A, np = a.n_atoms * 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nx + np) return;
+  const bool is_pos = i >= nx;
+  const int64_t j = is_pos ? i - nx : i;
+  float v = (is_pos ? a.eps_pos : a.eps_x)[j];
+  const float* eu = is_pos ? a.eps_pos_uncond : a.eps_x_uncond;
+  if (eu != nullptr) {
+    const float u = eu[j];
+    v = u + a.guidance_scale * (v - u);
+  }
+  const int64_t atom = is_pos ? j / 3 : j / LD_A;
+  if (!(fabsf(v) <= 100.0f)) reject[atom_mol[atom]] = 1;  // also true for NaN
+}
+
+// Shared loop of the DDPM sampler (ddim_ts == NULL: step index counts down from n_steps - 1 and is the
+// timestep) and of the DDIM sampler (ddim_ts [n_steps] device int32: loop position counts up, the
+// timestep is ddim_ts[position]; `reject` [n_mols] collects the per-step prediction gate).
+static int sample_loop(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                       const float* properties, float guidance_scale, float temperature, const float* betas,
+                       const float* alphas, const float* alphas_cumprod, int32_t n_steps, uint64_t seed,
+                       int64_t atom_offset, int use_graph, void* workspace, size_t workspace_bytes, void* stream,
+                       const int32_t* ddim_ts, int32_t* reject) {
+  const bool ddim = ddim_ts != nullptr;
+  if (!weights || !graph || !x || !pos || !alphas_cumprod || !workspace || n_steps <= 0) return LIGDIFF_ERR_ARG;
+  if (!ddim && (!betas || !alphas)) return LIGDIFF_ERR_ARG;
+  if (ddim && !reject) return LIGDIFF_ERR_ARG;
   if (use_graph && stream == nullptr) return LIGDIFF_ERR_ARG;  // the default stream cannot be captured
   // generation.py:428: guidance only when properties are given AND scale > 1
   const int guided = (properties != nullptr && guidance_scale > 1.0f) ? 1 : 0;
@@ -295,8 +353,11 @@ extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_gr
   int32_t* counter = (int32_t*)(ws + L.t_index);   // [0] next step index, [1] index of the step in progress
   auto WF = [&](size_t off) { return (float*)(ws + off); };
 
-  // tables for t = 0 .. n_steps-1
-  hipLaunchKernelGGL(k_iota_float, dim3(ceil_div(n_steps, 256)), dim3(256), 0, s, WF(L.tvals), n_steps);
+  // table rows: DDPM row t <-> timestep t; DDIM row i <-> timestep ddim_ts[i]
+  if (ddim)
+    hipLaunchKernelGGL(k_int_to_float, dim3(ceil_div(n_steps, 256)), dim3(256), 0, s, ddim_ts, WF(L.tvals), n_steps);
+  else
+    hipLaunchKernelGGL(k_iota_float, dim3(ceil_div(n_steps, 256)), dim3(256), 0, s, WF(L.tvals), n_steps);
   int rc = run_time_rows(weights, WF(L.tvals), n_steps, WF(L.tf), WF(L.t1), WF(L.tab_temb), WF(L.stemb),
                          WF(L.tab_mod[0]), WF(L.tab_mod[1]), WF(L.tab_mod[2]), s);
   if (rc) return rc;
@@ -318,7 +379,7 @@ extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_gr
   const int base = LIGDIFF_FWD_T_BROADCAST | LIGDIFF_FWD_SKIP_PROP_HEAD | FWD_INTERNAL_TIME_GIVEN;
   auto one_step = [&]() -> int {
     hipLaunchKernelGGL(k_time_gather, dim3(5), dim3(256), 0, s, counter, tg);
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, counter);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, counter, ddim ? 1 : -1);
     int r = run_forward(weights, graph, x, pos, nullptr, counter + 1, properties,
                         base | (properties ? LIGDIFF_FWD_PROPERTIES : 0), WF(L.eps_x), WF(L.eps_pos), nullptr,
                         ws + L.fwd, s);
@@ -328,11 +389,18 @@ extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_gr
                       ws + L.fwd, s);
       if (r) return r;
     }
-    launch_reverse_step_ddpm(&a, s);
+    if (ddim) {
+      const int64_t n = a.n_atoms * (LD_A + 3);
+      hipLaunchKernelGGL(k_prediction_gate_guided, dim3(ceil_div(n, 256)), dim3(256), 0, s, a, graph->atom_mol, reject);
+      hipLaunchKernelGGL(k_reverse_step_ddim_list, dim3(ceil_div(n, 256)), dim3(256), 0, s, a, ddim_ts, n_steps,
+                         (const int32_t*)(counter + 1));
+    } else {
+      launch_reverse_step_ddpm(&a, s);
+    }
     return hipGetLastError() == hipSuccess ? LIGDIFF_OK : LIGDIFF_ERR_LAUNCH;
   };
 
-  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, counter, n_steps - 1);
+  hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, counter, ddim ? 0 : n_steps - 1);
   if (!use_graph) {
     for (int i = 0; i < n_steps; ++i) {
       rc = one_step();
@@ -372,6 +440,25 @@ extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_gr
   if (exec4) (void)hipGraphExecDestroy(exec4);
   if (exec1) (void)hipGraphExecDestroy(exec1);
   return rc;
+}
+
+extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                                   const float* properties, float guidance_scale, float temperature,
+                                   const float* betas, const float* alphas, const float* alphas_cumprod,
+                                   int32_t n_steps, uint64_t seed, int64_t atom_offset, int use_graph,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!betas || !alphas) return LIGDIFF_ERR_ARG;
+  return sample_loop(weights, graph, x, pos, properties, guidance_scale, temperature, betas, alphas, alphas_cumprod,
+                     n_steps, seed, atom_offset, use_graph, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int ligdiff_ddim_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                                   const float* properties, float guidance_scale, const float* alphas_cumprod,
+                                   const int32_t* timesteps, int32_t n_steps, int32_t* reject, int use_graph,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!timesteps || !reject) return LIGDIFF_ERR_ARG;
+  return sample_loop(weights, graph, x, pos, properties, guidance_scale, 1.0f, nullptr, nullptr, alphas_cumprod, n_steps,
+                     0, 0, use_graph, workspace, workspace_bytes, stream, timesteps, reject);
 }
 
 // ------------------------------------------------------------------ acceptance gates

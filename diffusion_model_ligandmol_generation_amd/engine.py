@@ -291,6 +291,36 @@ class ScoreNetworkEngine:
                 cur.wait_stream(run_on)
         check(rc, "ligdiff_ddpm_sample")
 
+    def ddim_sample(self, model, graph, x, pos, timesteps, reject, properties=None, guidance_scale=1.0,
+                    use_graph=True):
+        """Whole DDIM loop in the library (ligdiff_ddim_sample); x / pos updated in place, ``reject``
+        [B] int32 receives the per-step prediction gate.  timesteps: list of ints."""
+        n_steps = len(timesteps)
+        guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
+        nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
+                                                              n_steps)
+        ws = self.workspace(nbytes)
+        ts = torch.tensor([int(t) for t in timesteps], dtype=torch.int32, device=self.device)
+        if properties is not None:
+            properties = properties.contiguous().float()
+            if properties.shape != (graph.n_mols, 15):
+                raise ValueError("properties must be [B,15]")
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream()
+            run_on = cur
+            if use_graph and cur.cuda_stream == 0:     # the legacy default stream cannot be captured
+                if getattr(self, "_side", None) is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                run_on = self._side
+                run_on.wait_stream(cur)
+            with torch.cuda.stream(run_on):
+                rc = self.lib.ligdiff_ddim_sample(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
+                                                  float(guidance_scale), _ptr(model.alphas_cumprod), _ptr(ts), n_steps,
+                                                  _ptr(reject), 1 if use_graph else 0, _ptr(ws), ws.numel(), _stream())
+            if run_on is not cur:
+                cur.wait_stream(run_on)
+        check(rc, "ligdiff_ddim_sample")
+
     def philox_normal(self, n, seed, step, stream_id, offset=0, scale=1.0):
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

@@ -122,6 +122,9 @@ class ResearchValidatedGenerator:
         t_index = torch.zeros(1, dtype=torch.int32, device=dev)
         if use_ddim:
             steps = torch.linspace(T - 1, 0, num_steps, dtype=torch.long).tolist()  # generation.py:305
+            if noise is None and trace is None:
+                eng.ddim_sample(model, graph, x, pos, steps, rejected, props, guidance_scale, use_graph)
+                return x, pos, graph, rejected
         else:
             steps = list(range(T - 1, -1, -1))                                    # generation.py:422
         for i, t in enumerate(steps):

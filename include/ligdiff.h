@@ -281,6 +281,19 @@ int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph,
 size_t ligdiff_ddpm_sample_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided,
                                            int32_t n_steps);
 
+/* Whole DDIM loop of generation.py:279-381 (the generator's default mode), same structure as
+ * ligdiff_ddpm_sample: timesteps [n_steps] (device int32, generation.py:305: linspace(T-1, 0,
+ * n_steps) truncated) are walked front to back; the update of position i uses
+ * alphas_cumprod[timesteps[i]] and alphas_cumprod[timesteps[i+1]] (the last step returns the x0
+ * estimate).  reject [n_mols] (device int32, zeroed by the caller) receives 1 for every molecule
+ * whose guidance-combined prediction failed the per-step gate of generation.py:351 / :518-541
+ * (the loop still runs it to the end: molecules are independent).  No noise is drawn.  Workspace:
+ * ligdiff_ddpm_sample_workspace_bytes with the same arguments. */
+int ligdiff_ddim_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                        const float* properties, float guidance_scale, const float* alphas_cumprod,
+                        const int32_t* timesteps, int32_t n_steps, int32_t* reject, int use_graph,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fills out[n] with the N(0,1) draws the in-kernel Philox stream yields for
  * (seed, step, global element index offset..offset+n): lets a host reproduce a run. */
 int ligdiff_philox_normal(float* out, int64_t n, uint64_t seed, uint32_t step, uint32_t stream_id,
