@@ -257,24 +257,26 @@ __global__ void k_iota_float(float* v, int n) {
   if (i < n) v[i] = (float)i;
 }
 
-// Step prologue: row t = counter[0] of the tables -> the forward's temb / mod buffers.
+// Step prologue, ONE workgroup: row r = counter[0] of the tables -> the forward's temb / mod buffers
+// (1216 float4), then counter[1] = r (index of the step now in progress, read by its update
+// kernel) and counter[0] = r + delta (the next one).  A single workgroup so that the counter can be
+// advanced after its barrier: every thread has read counter[0] by then.
 struct TimeGatherArgs { const float* tab_temb; const float* tab_mod[3]; float* temb; float* mod[3]; };
-__global__ __launch_bounds__(256) void k_time_gather(const int32_t* counter, TimeGatherArgs p) {
+__global__ __launch_bounds__(1024) void k_step_prologue(int32_t* counter, TimeGatherArgs p, int delta) {
   const int t = counter[0];
-  const int i = blockIdx.x * 256 + threadIdx.x;    // float4 index within the 4864-float row
-  if (i < 64) {
-    reinterpret_cast<f32x4*>(p.temb)[i] = reinterpret_cast<const f32x4*>(p.tab_temb + (size_t)t * 256)[i];
-  } else if (i < 64 + 3 * 384) {
-    const int l = (i - 64) / 384, j = (i - 64) % 384;
-    reinterpret_cast<f32x4*>(p.mod[l])[j] = reinterpret_cast<const f32x4*>(p.tab_mod[l] + (size_t)t * 1536)[j];
+  for (int i = threadIdx.x; i < 64 + 3 * 384; i += 1024) {
+    if (i < 64) {
+      reinterpret_cast<f32x4*>(p.temb)[i] = reinterpret_cast<const f32x4*>(p.tab_temb + (size_t)t * 256)[i];
+    } else {
+      const int l = (i - 64) / 384, j = (i - 64) % 384;
+      reinterpret_cast<f32x4*>(p.mod[l])[j] = reinterpret_cast<const f32x4*>(p.tab_mod[l] + (size_t)t * 1536)[j];
+    }
   }
-}
-// counter[1] = index of the step now in progress (read by its update kernel), counter[0] = the next
-// one.  A launch of its own, after the gather: every block of the gather reads counter[0].
-__global__ void k_advance(int32_t* counter, int delta) {
-  const int t = counter[0];
-  counter[1] = t;
-  counter[0] = t + delta;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counter[1] = t;
+    counter[0] = t + delta;
+  }
 }
 __global__ void k_int_to_float(const int32_t* in, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -378,8 +380,7 @@ static int sample_loop(const float* const* weights, const ligdiff_graph* graph, 
 
   const int base = LIGDIFF_FWD_T_BROADCAST | LIGDIFF_FWD_SKIP_PROP_HEAD | FWD_INTERNAL_TIME_GIVEN;
   auto one_step = [&]() -> int {
-    hipLaunchKernelGGL(k_time_gather, dim3(5), dim3(256), 0, s, counter, tg);
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, counter, ddim ? 1 : -1);
+    hipLaunchKernelGGL(k_step_prologue, dim3(1), dim3(1024), 0, s, counter, tg, ddim ? 1 : -1);
     int r = run_forward(weights, graph, x, pos, nullptr, counter + 1, properties,
                         base | (properties ? LIGDIFF_FWD_PROPERTIES : 0), WF(L.eps_x), WF(L.eps_pos), nullptr,
                         ws + L.fwd, s);

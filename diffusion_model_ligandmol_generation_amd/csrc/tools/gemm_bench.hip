@@ -280,6 +280,39 @@ int main() {
     RUN_DBG(2, "dbg2 no DMA, no barrier")
     RUN_DBG(3, "dbg3 MFMA only")
   }
+  printf("--- two independent GEMMs: back to back on one stream vs on two streams\n");
+  {
+    hipStream_t s1, s2;
+    CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+    hipEvent_t e0, e1, ej;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&ej));
+    // node MLP-1 shape (M=N atoms, K=512, 256 columns, SiLU) and coordinate-gate shape (M=E edges, K=256, 128 columns)
+    GemmCore ga = core(M, 512, 1, 512);
+    APtrPlain apa{A, 512};
+    EpiBiasAct<8, ACT_SILU, false> ea; memset(&ea, 0, sizeof ea);
+    ea.M = M; ea.n_valid = 256; ea.col_block = 256; ea.C = C; ea.ldc = 256; ea.alpha = 1.f; ea.bias[0] = bias;
+    GemmCore gb; memset(&gb, 0, sizeof gb);
+    gb.M = E; gb.K = 256; gb.n_valid = 128; gb.ldw = 256; gb.W[0] = W;
+    APtrPlain apb{A + (size_t)M * 512, 256};
+    EpiBiasAct<4, ACT_SILU, false> eb; memset(&eb, 0, sizeof eb);
+    eb.M = E; eb.n_valid = 128; eb.col_block = 128; eb.C = C2; eb.ldc = 128; eb.alpha = 1.f; eb.bias[0] = bias;
+    auto la = [&](hipStream_t st) { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiBiasAct<8, ACT_SILU, false>>), dim3(232, 1), dim3(512), 0, st, ga, apa, ea); };
+    auto lb = [&](hipStream_t st) { hipLaunchKernelGGL((gemm_rows2_kernel<4, APtrPlain, EpiBiasAct<4, ACT_SILU, false>>), dim3(496, 1), dim3(256), 0, st, gb, apb, eb); };
+    for (int mode = 0; mode < 2; ++mode) {
+      for (int w = 0; w < 3; ++w) { la(s1); lb(mode ? s2 : s1); }
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0, s1));
+      for (int r = 0; r < 20; ++r) {
+        if (mode) { CK(hipEventRecord(ej, s1)); CK(hipStreamWaitEvent(s2, ej, 0)); }
+        la(s1); lb(mode ? s2 : s1);
+        if (mode) { CK(hipEventRecord(ej, s2)); CK(hipStreamWaitEvent(s1, ej, 0)); }
+      }
+      CK(hipEventRecord(e1, s1));
+      CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("%-44s %8.1f us per pair\n", mode ? "two streams (fork/join per pair)" : "one stream", ms / 20 * 1e3);
+    }
+  }
   printf("--- cold operands: rotating over 6 buffer sets (A, resid, C each 30 MB; W 6 copies)\n");
   {
     float* big;
