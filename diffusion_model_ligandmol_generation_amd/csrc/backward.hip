@@ -222,12 +222,30 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
       colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_OUT_B)], s);
     gemm_dx<8, MUL_NONE, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_OUT_W)], 256, 256, t256c, 256, nullptr, 0, s);
     float* dqkv = T(L.n768);
-    if (g->max_mol_atoms <= 64) {
-      hipLaunchKernelGGL(k_attention_bwd, dim3(B * 2), dim3(256), att_lds_hpb4, s, A(F.qkv[l]), A(F.att[l]), t256c,
-                         A(F.lse[l]), g->mol_ptr, dqkv, 64);
+    if (getenv("LIGDIFF_ATT_BWD_V1") != nullptr) {   // scalar reference kernel (A/B switch used by the tests)
+      if (g->max_mol_atoms <= 64)
+        hipLaunchKernelGGL(k_attention_bwd, dim3(B * 2), dim3(256), att_lds_hpb4, s, A(F.qkv[l]), A(F.att[l]), t256c,
+                           A(F.lse[l]), g->mol_ptr, dqkv, 64);
+      else
+        hipLaunchKernelGGL(k_attention_bwd, dim3(B * 4), dim3(128), att_lds_hpb4 / 2, s, A(F.qkv[l]), A(F.att[l]), t256c,
+                           A(F.lse[l]), g->mol_ptr, dqkv, 128);
     } else {
-      hipLaunchKernelGGL(k_attention_bwd, dim3(B * 4), dim3(128), att_lds_hpb4 / 2, s, A(F.qkv[l]), A(F.att[l]), t256c,
-                         A(F.lse[l]), g->mol_ptr, dqkv, 128);
+      const int tk = (g->max_mol_atoms + 31) / 32;
+      const float* qkv_l = A(F.qkv[l]);
+      const float* att_l = A(F.att[l]);
+      const float* lse_l = A(F.lse[l]);
+      if (tk == 1)
+        hipLaunchKernelGGL((k_attention_bwd_mfma<1, 4>), dim3(ceil_div((long)B * 8, 4)), dim3(256), 4 * 32 * 134 * 4, s, qkv_l,
+                           att_l, t256c, lse_l, g->mol_ptr, dqkv, B);
+      else if (tk == 2)
+        hipLaunchKernelGGL((k_attention_bwd_mfma<2, 4>), dim3(ceil_div((long)B * 8, 4)), dim3(256), 4 * 64 * 134 * 4, s, qkv_l,
+                           att_l, t256c, lse_l, g->mol_ptr, dqkv, B);
+      else if (tk == 3)
+        hipLaunchKernelGGL((k_attention_bwd_mfma<3, 2>), dim3(ceil_div((long)B * 8, 2)), dim3(128), 2 * 96 * 134 * 4, s, qkv_l,
+                           att_l, t256c, lse_l, g->mol_ptr, dqkv, B);
+      else
+        hipLaunchKernelGGL((k_attention_bwd_mfma<4, 2>), dim3(ceil_div((long)B * 8, 2)), dim3(128), 2 * 128 * 134 * 4, s, qkv_l,
+                           att_l, t256c, lse_l, g->mol_ptr, dqkv, B);
     }
     if (!gemm_dw<8>(dqkv, 768, 768, A(F.xn1[l]), 256, 256, N, gr[W_DIT(l, DIT_INP_W)], 256, s, gr[W_DIT(l, DIT_INP_B)]))
       colsum(dqkv, 768, N, 768, nullptr, gr[W_DIT(l, DIT_INP_B)], s);

@@ -233,6 +233,157 @@ __global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__
   }
 }
 
+// MFMA form of the attention backward (fp32 v_mfma_f32_32x32x2_f32), one wave per (molecule, head),
+// WPB waves per workgroup, TK = number of 32-atom tiles (n <= 32 TK).  q, k, v, dO of the head sit in
+// LDS as [n][33] (zero rows beyond n), lse and delta_i = dO_i . O_i as [n].  As in the forward
+// kernel a product whose result feeds the next product is computed TRANSPOSED, so that its
+// accumulator (lane = column, register = row) can be used directly as the B operand:
+//   pass 1, lane = query i:  S^T = K Q'^T, dP^T = V dO^T  ->  dS^T = P^T (dP^T - delta_i)
+//                            dQ^T[d, i] = sum_j K[j, d] dS^T[j, i]
+//   pass 2, lane = key j:    S = Q' K^T, dP = dO V^T      ->  P, dS (row statistics read per register)
+//                            dV^T[d, j] = sum_i dO[i, d] P[i, j],  dK^T[d, j] = sum_i Q[i, d] dS[i, j]
+// with Q' = Q / sqrt(32); dQ and dK carry the same factor.  Register r of lane half h is row
+// (r & 3) + 8 (r >> 2) + 4 h of a tile.
+#define GB_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
+template <int TK, int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_attention_bwd_mfma(const float* __restrict__ qkv, const float* __restrict__ o,
+                                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                                 const int32_t* __restrict__ mol_ptr,
+                                                                 float* __restrict__ dqkv, int n_mols) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NP = TK * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = blockIdx.x * WPB + wave;
+  const int mol = item >> 3, head = item & 7;
+  float* sq = smem + (size_t)wave * (NP * 134);
+  float* sk = sq + NP * 33;
+  float* sv = sk + NP * 33;
+  float* sdo = sv + NP * 33;
+  float* slse = sdo + NP * 33;
+  float* sdel = slse + NP;
+  int a0 = 0, n = 0;
+  if (mol < n_mols) { a0 = mol_ptr[mol]; n = mol_ptr[mol + 1] - a0; }
+  for (int i = lane; i < NP * 8; i += 64) {   // 8 lanes per row, 4 columns each
+    const int j = i >> 3, c = (i & 7) * 4;
+    f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, v4 = q4, d4 = q4, o4 = q4;
+    if (j < n) {
+      const float* r = qkv + (size_t)(a0 + j) * 768 + head * 32 + c;
+      q4 = *reinterpret_cast<const f32x4*>(r);
+      k4 = *reinterpret_cast<const f32x4*>(r + 256);
+      v4 = *reinterpret_cast<const f32x4*>(r + 512);
+      d4 = *reinterpret_cast<const f32x4*>(d_o + (size_t)(a0 + j) * 256 + head * 32 + c);
+      o4 = *reinterpret_cast<const f32x4*>(o + (size_t)(a0 + j) * 256 + head * 32 + c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sq[j * 33 + c + e] = q4[e]; sk[j * 33 + c + e] = k4[e]; sv[j * 33 + c + e] = v4[e]; sdo[j * 33 + c + e] = d4[e];
+    }
+    float dl = (d4[0] * o4[0] + d4[1] * o4[1]) + (d4[2] * o4[2] + d4[3] * o4[3]);
+    dl += __shfl_xor(dl, 1); dl += __shfl_xor(dl, 2); dl += __shfl_xor(dl, 4);
+    if ((i & 7) == 0) {
+      sdel[j] = dl;
+      slse[j] = j < n ? lse[(size_t)(a0 + j) * 8 + head] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (mol >= n_mols) return;
+  const int fi = lane & 31, h = lane >> 5;
+  const float scale = 0.17677669529663687f;
+  // ---------------- pass 1: lane = query
+#pragma unroll 1
+  for (int it = 0; it < TK; ++it) {
+    if (it * 32 >= n) break;
+    const int qi = it * 32 + fi;
+    float qreg[16], doreg[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { qreg[s] = sq[qi * 33 + 2 * s + h] * scale; doreg[s] = sdo[qi * 33 + 2 * s + h]; }
+    const float lse_i = slse[qi], del_i = sdel[qi];
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll 1
+    for (int jt = 0; jt < TK; ++jt) {
+      if (jt * 32 >= n) break;
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+      const float* krow = sk + (jt * 32 + fi) * 33 + h;
+      const float* vrow = sv + (jt * 32 + fi) * 33 + h;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * s], qreg[s], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[2 * s], doreg[s], dpt, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = jt * 32 + GB_ROW(r, h);
+        const float p = (j < n && qi < n) ? __expf(st[r] - lse_i) : 0.f;
+        st[r] = p * (dpt[r] - del_i);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dq = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[(jt * 32 + GB_ROW(r, h)) * 33 + fi], st[r], dq, 0, 0, 0);
+    }
+    if (qi < n) {
+      float* out = dqkv + (size_t)(a0 + qi) * 768 + head * 32;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {   // registers 4g..4g+3 are d = 8g + 4h + (0..3)
+        const f32x4 v = {dq[gq * 4 + 0] * scale, dq[gq * 4 + 1] * scale, dq[gq * 4 + 2] * scale, dq[gq * 4 + 3] * scale};
+        *reinterpret_cast<f32x4*>(out + gq * 8 + h * 4) = v;
+      }
+    }
+  }
+  // ---------------- pass 2: lane = key
+#pragma unroll 1
+  for (int jt = 0; jt < TK; ++jt) {
+    if (jt * 32 >= n) break;
+    const int kj = jt * 32 + fi;
+    float kreg[16], vreg[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { kreg[s] = sk[kj * 33 + 2 * s + h]; vreg[s] = sv[kj * 33 + 2 * s + h]; }
+    f32x16 dk, dv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+#pragma unroll 1
+    for (int it = 0; it < TK; ++it) {
+      if (it * 32 >= n) break;
+      f32x16 sm, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sm[r] = 0.f; dp[r] = 0.f; }
+      const float* qrow = sq + (it * 32 + fi) * 33 + h;
+      const float* drow = sdo + (it * 32 + fi) * 33 + h;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        sm = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[2 * s] * scale, kreg[s], sm, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[2 * s], vreg[s], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = it * 32 + GB_ROW(r, h);
+        const float p = (i < n && kj < n) ? __expf(sm[r] - slse[i]) : 0.f;
+        sm[r] = p;
+        dp[r] = p * (dp[r] - sdel[i]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = it * 32 + GB_ROW(r, h);
+        dv = __builtin_amdgcn_mfma_f32_32x32x2f32(sdo[i * 33 + fi], sm[r], dv, 0, 0, 0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x2f32(sq[i * 33 + fi], dp[r], dk, 0, 0, 0);
+      }
+    }
+    if (kj < n) {
+      float* out = dqkv + (size_t)(a0 + kj) * 768 + head * 32;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 kv = {dk[gq * 4 + 0] * scale, dk[gq * 4 + 1] * scale, dk[gq * 4 + 2] * scale, dk[gq * 4 + 3] * scale};
+        const f32x4 vv = {dv[gq * 4 + 0], dv[gq * 4 + 1], dv[gq * 4 + 2], dv[gq * 4 + 3]};
+        *reinterpret_cast<f32x4*>(out + 256 + gq * 8 + h * 4) = kv;
+        *reinterpret_cast<f32x4*>(out + 512 + gq * 8 + h * 4) = vv;
+      }
+    }
+  }
+}
+
 // Coordinate-gate backward (model1.py:106-112), one wave per edge, strided over the grid:
 //   dwrel = 0.1 (G[dst] - G[src]);  dcw = dwrel . rel;  ds = dcw (1 - cw^2)
 //   drel  = dwrel cw;  dhc_pre[j] = ds w2[j] silu'(hc_pre[j]);  dw2[j] += ds silu(hc_pre[j]);  db2 += ds
