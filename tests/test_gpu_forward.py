@@ -159,3 +159,36 @@ def test_consistency_batched_matches_oracle_ragged():
         got = m(Bag(x=x.cuda(), pos=pos.cuda(), edge_index=ei.cuda(), batch=b.cuda()), t.cuda())[3]
     for g_, w_ in zip(got, want):
         torch.testing.assert_close(g_.cpu(), w_, rtol=RTOL, atol=ATOL)
+
+
+def test_forward_full_benchmark_batch_matches_oracle_and_splits():
+    """BASELINE config 2 size (1024 x 29-atom template ligands, N = 29 696, E = 63 488): one forward
+    against the CPU restatement, plus two size-independent properties: the launch is deterministic
+    (bitwise equal when repeated) and molecules are independent (the batch equals the concatenation
+    of its two halves run separately, to rounding: row tiles fall differently)."""
+    import copy
+    m = copy.deepcopy(seed0_model()).cuda().eval()
+    sd = seed0_state_dict()
+    c = _random_batch([29] * 1024, 2024)
+    x, pos, ei, b = (torch.from_numpy(c[k]) for k in ("x", "pos", "edge_index", "batch"))
+    t = (torch.arange(1024, dtype=torch.float32) * 13.0) % 1000
+    with torch.no_grad():
+        ea, ep, er = oracle.score_network_forward(sd, x, pos, ei, b, t, None, pad_to_max_atoms=False)
+        bag = Bag(x=x.cuda(), pos=pos.cuda(), edge_index=ei.cuda(), batch=b.cuda())
+        a, p, r, _ = m(bag, t.cuda())
+        a_again, p_again, r_again, _ = m(bag, t.cuda())
+    torch.testing.assert_close(a.cpu(), ea, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(p.cpu(), ep, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(r.cpu(), er, rtol=RTOL, atol=ATOL)
+    assert torch.equal(a, a_again) and torch.equal(p, p_again) and torch.equal(r, r_again)
+    half_atoms, half_edges = 512 * 29, int((ei[0] < 512 * 29).sum())
+    with torch.no_grad():
+        lo = Bag(x=x[:half_atoms].cuda(), pos=pos[:half_atoms].cuda(), edge_index=ei[:, :half_edges].cuda(),
+                 batch=b[:half_atoms].cuda())
+        hi = Bag(x=x[half_atoms:].cuda(), pos=pos[half_atoms:].cuda(), edge_index=(ei[:, half_edges:] - half_atoms).cuda(),
+                 batch=(b[half_atoms:] - 512).cuda())
+        a1, p1, r1, _ = m(lo, t[:512].cuda())
+        a2, p2, r2, _ = m(hi, t[512:].cuda())
+    torch.testing.assert_close(torch.cat([a1, a2]), a, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(torch.cat([p1, p2]), p, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(torch.cat([r1, r2]), r, rtol=1e-5, atol=1e-5)
