@@ -353,7 +353,15 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         EpiCoord e{E, w[W_E3(l, E3_CN0_B)], w[W_E3(l, E3_CN2_W)], w[W_E3(l, E3_CN2_B)],
                           F(L.rel[l]), F(L.wrel[l]), S(L.hc_pre[l]), S(L.cw[l])};
         PB("e3_%d.coord", l);
-        launch_gemm_plain<4>(gc, F(L.msg[l]), 256, e, 1, s);
+        // E = 2 x atoms rows already give two 4-wave workgroups per CU; the eight-wave form measured
+        // slower here (its dot-product head needs the mailbox exchange and a barrier)
+        if (use_gemm2()) {
+          hipLaunchKernelGGL((gemm_rows2_kernel<4, APtrPlain, EpiCoord>), dim3(ceil_div(E, G_BM), 1), dim3(256), 0, s, gc,
+                             APtrPlain{F(L.msg[l]), 256}, e);
+        } else {
+          ALoadPlain alc{F(L.msg[l]), 256, E, 256};
+          launch_gemm<4, W_ALIGNED>(gc, alc, e, 1, s);
+        }
         PE();
       }
     }

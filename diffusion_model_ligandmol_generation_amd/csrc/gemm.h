@@ -227,43 +227,53 @@ struct EpiBiasAct {
       }
     }
   }
-  // Column-split form.  The optional outputs are a template switch so that the row loop has
-  // no per-element branch, and GELU runs two columns at a time on packed fp32 instructions.
-  template <bool PRE, class MB>
-  __device__ __forceinline__ void cs_body(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB&) const {
-    const int c0 = lane & 31;
+  // Column-split form (NW accumulators per wave: columns [32 NW half, 32 NW (half + 1)) of the block).
+  // The optional outputs are a template switch so that the row loop has no per-element branch, and
+  // GELU runs two columns at a time on packed fp32 instructions.
+  template <bool PRE, int NW, class MB>
+  __device__ __forceinline__ void cs_body(f32x16 (&acc)[NW], int row0, int by, int half, int lane, const MB&) const {
+    const int c0 = half * 32 * NW + (lane & 31);
     const float* b = bias[by];
-    float bv[4];
+    float bv[NW];
+    bool ok[NW];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) bv[ct] = b != nullptr ? b[half * 128 + ct * 32 + c0] : 0.f;
+    for (int ct = 0; ct < NW; ++ct) {
+      ok[ct] = c0 + ct * 32 < n_valid;
+      bv[ct] = (b != nullptr && ok[ct]) ? b[c0 + ct * 32] : 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + G_ROW(r, lane);
       if (row < M) {
-        const size_t o0 = (size_t)row * ldc + (size_t)by * col_block + half * 128 + c0;
-        float u[4], v[4];
+        const size_t o0 = (size_t)row * ldc + (size_t)by * col_block + c0;
+        float u[NW], v[NW];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) u[ct] = acc[ct][r] * alpha + bv[ct];
+        for (int ct = 0; ct < NW; ++ct) u[ct] = acc[ct][r] * alpha + bv[ct];
         if (ACT == ACT_GELU) {
-          const f32x2 g0 = gelu_exact2(f32x2{u[0], u[1]}), g1 = gelu_exact2(f32x2{u[2], u[3]});
-          v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+#pragma unroll
+          for (int ct = 0; ct < NW; ct += 2) {
+            const f32x2 g0 = gelu_exact2(f32x2{u[ct], u[ct + 1]});
+            v[ct] = g0[0]; v[ct + 1] = g0[1];
+          }
         } else {
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) v[ct] = apply_act<ACT>(u[ct]);
+          for (int ct = 0; ct < NW; ++ct) v[ct] = apply_act<ACT>(u[ct]);
         }
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          C[o0 + ct * 32] = v[ct];
-          if (PRE) pre_out[o0 + ct * 32] = u[ct];
-          if (DUAL_SILU) C2[o0 + ct * 32] = silu(v[ct]);
+        for (int ct = 0; ct < NW; ++ct) {
+          if (NW == 4 || ok[ct]) {   // 256-column blocks are always full
+            C[o0 + ct * 32] = v[ct];
+            if (PRE) pre_out[o0 + ct * 32] = u[ct];
+            if (DUAL_SILU) C2[o0 + ct * 32] = silu(v[ct]);
+          }
         }
       }
     }
   }
-  template <class MB>
-  __device__ __forceinline__ void cs(f32x16 (&acc)[4], int row0, int by, int half, int lane, const MB& mb) const {
-    if (pre_out != nullptr) cs_body<true>(acc, row0, by, half, lane, mb);
-    else cs_body<false>(acc, row0, by, half, lane, mb);
+  template <int NW, class MB>
+  __device__ __forceinline__ void cs(f32x16 (&acc)[NW], int row0, int by, int half, int lane, const MB& mb) const {
+    if (pre_out != nullptr) cs_body<true, NW>(acc, row0, by, half, lane, mb);
+    else cs_body<false, NW>(acc, row0, by, half, lane, mb);
   }
 };
 

@@ -42,11 +42,19 @@ struct HalfMailbox {
   }
 };
 
-template <class AP, class EPI>
+// s_waitcnt vmcnt(N) alone (expcnt / lgkmcnt fields left at their maxima)
+template <int N>
+__device__ __forceinline__ void wait_vm_count() {
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+// NTW = accumulators per wave: 4 -> 256-column blocks (the common case), 2 -> 128-column blocks
+// (coordinate gate, atom head), whose stage is 128 + 128 rows and whose waves issue two DMAs per chunk.
+template <class AP, class EPI, int NTW = 4>
 __global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI epi) {
-  __shared__ __attribute__((aligned(1024))) float smem3[G3_LDS_BYTES / 4];
   constexpr int A_FL = 128 * G2_ROWF;
-  constexpr int ST = G3_STAGE_FLOATS;
+  constexpr int ST = (128 + 64 * NTW) * G2_ROWF;
+  __shared__ __attribute__((aligned(1024))) float smem3[3 * ST + 4 * 256];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,21 +63,21 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI 
   const int row_blk = blockIdx.x * 128;
   const float* __restrict__ W = g.W[by];
 
-  f32x16 acc[4];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int ct = 0; ct < NTW; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 
-  // DMA roles (see gemm2.h): one A piece (16 rows) and two W pieces per wave and chunk
+  // DMA roles (see gemm2.h): one A piece (16 rows) and NTW/2 W pieces per wave and chunk
   const int pr = lane >> 2, ps = lane & 3;
   const int lslot = ps ^ ((pr >> 2) & 3);
   int a_row = row_blk + wave * 16 + pr;
   a_row = a_row < g.M ? a_row : g.M - 1;
-  const float* w_src[2];
+  const float* w_src[NTW / 2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int n = (wave * 2 + i) * 16 + pr;
+  for (int i = 0; i < NTW / 2; ++i) {
+    int n = (wave * (NTW / 2) + i) * 16 + pr;
     n = n < g.n_valid ? n : g.n_valid - 1;
     w_src[i] = W + (size_t)n * g.ldw + lslot * 4;
   }
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI 
     const int k0 = kc * G2_BK;
     lds_dma16(ap.ptr(a_row, k0 + lslot * 4), sA + wave * 256);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) lds_dma16(w_src[i] + k0, sW + (wave * 2 + i) * 256);
+    for (int i = 0; i < NTW / 2; ++i) lds_dma16(w_src[i] + k0, sW + (wave * (NTW / 2) + i) * 256);
   };
 
   const int nk = g.K / G2_BK;
@@ -92,12 +100,12 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI 
   for (int kc = 0; kc < nk; ++kc) {
     // own DMAs of chunk kc done (the newest chunk may stay in flight), then join: every
     // wave's part of chunk kc is in LDS and nobody still reads the stage refilled below
-    if (kc + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F73);   // vmcnt(3)
-    else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+    if (kc + 1 < nk) wait_vm_count<1 + NTW / 2>();
+    else wait_vm_count<0>();
     __builtin_amdgcn_s_barrier();
     if (kc + 2 < nk) issue(kc + 2, cur == 0 ? 2 : cur - 1);
     const float* sA = smem3 + cur * ST;
-    const float* sW = sA + A_FL + (half * 128 + fi) * G2_ROWF;
+    const float* sW = sA + A_FL + (half * 32 * NTW + fi) * G2_ROWF;
     const float* arow = sA + (slab * 32 + fi) * G2_ROWF;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + off0);
     const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + off1);
@@ -105,12 +113,12 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI 
     b[0][0] = *reinterpret_cast<const f32x4*>(sW + off0);
     b[0][1] = *reinterpret_cast<const f32x4*>(sW + off1);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
+    for (int ct = 0; ct < NTW; ++ct) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[ct & 1][0][j], acc[ct], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (ct + 1 < 4) {
+      if (ct + 1 < NTW) {
         b[(ct + 1) & 1][0] = *reinterpret_cast<const f32x4*>(sW + (ct + 1) * 32 * G2_ROWF + off0);
         b[(ct + 1) & 1][1] = *reinterpret_cast<const f32x4*>(sW + (ct + 1) * 32 * G2_ROWF + off1);
       }

@@ -29,10 +29,22 @@ static inline void launch_gemm_cs(const GemmCore& g, const AP& ap, const EPI& ep
   if (g.M <= 0) return;
   hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);
 }
+// 128-column blocks (n_valid <= 128 rows of W) on the eight-wave kernel with two accumulators per wave
+template <class AP, class EPI>
+static inline void launch_gemm_cs128(const GemmCore& g, const AP& ap, const EPI& epi, int nb, hipStream_t s) {
+  if (g.M <= 0) return;
+  hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);
+}
 template <int NT, class EPI>
 static inline void launch_gemm_plain(const GemmCore& g, const float* A, int lda, const EPI& epi, int nb, hipStream_t s) {
   if (g.M <= 0) return;
   dim3 grid(ceil_div(g.M, G_BM), nb);
+  if constexpr (NT == 4) {
+    if (use_cs() && (g.K % G2_BK) == 0 && (lda % 4) == 0 && (g.ldw % 4) == 0 && g.n_valid <= 128) {
+      launch_gemm_cs128(g, APtrPlain{A, lda}, epi, nb, s);
+      return;
+    }
+  }
   if constexpr (NT == 8) {
     if (use_cs() && (g.K % G2_BK) == 0 && (lda % 4) == 0 && (g.ldw % 4) == 0 && g.n_valid == 256) {
       launch_gemm_cs(g, APtrPlain{A, lda}, epi, nb, s);
