@@ -90,8 +90,10 @@ static bool gemm_dw(const float* dY, int lddy, int nout, const float* X, int ldx
                     int lddw, hipStream_t s, float* db = nullptr) {
   if (rows <= 0) return false;
   if (use_cs() && kin % 256 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && nout % 4 == 0 && nout >= 4) {
-    const int bx = ceil_div(nout, 128), by = kin / 256;
-    // every slice of the row range adds a full 128 x 256 tile with atomics, so the slice count is kept
+    // small gradients use 128-column tiles: twice the tiles, so half the slices per tile
+    const bool narrow = (long)ceil_div(nout, 128) * (kin / 256) <= 4;
+    const int bx = ceil_div(nout, 128), by = narrow ? kin / 128 : kin / 256;
+    // every slice of the row range adds a full tile with atomics, so the slice count is kept
     // near 1.5 workgroups per CU (measured best of 128 / 256 / 384 / 512 on the training step)
     static const int target_blocks = getenv("LIGDIFF_DW_BLOCKS") ? atoi(getenv("LIGDIFF_DW_BLOCKS")) : 384;
     int splits = ceil_div(target_blocks, bx * by);
@@ -101,7 +103,10 @@ static bool gemm_dw(const float* dY, int lddy, int nout, const float* X, int ldx
     const int m_split = (int)align_up(ceil_div(rows, splits), 16);
     splits = ceil_div(rows, m_split);
     GemmDwArgs a{dY, lddy, nout, X, ldx, kin, rows, m_split, dW, lddw, db};
-    hipLaunchKernelGGL(gemm_dw_kernel, dim3(bx, by, splits), dim3(512), 0, s, a);
+    if (narrow)
+      hipLaunchKernelGGL(gemm_dw_kernel<2>, dim3(bx, by, splits), dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL(gemm_dw_kernel<4>, dim3(bx, by, splits), dim3(512), 0, s, a);
     return db != nullptr;
   }
   OpK a{dY, lddy, nout, rows};

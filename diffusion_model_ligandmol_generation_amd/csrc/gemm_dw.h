@@ -14,32 +14,34 @@
 #pragma once
 #include "gemm2.h"
 
-#define GDW_STAGE_FLOATS (16 * 128 + 16 * 256)          // 24 KiB
-#define GDW_LDS_BYTES (3 * GDW_STAGE_FLOATS * 4)
+// NTW = accumulators per wave: 4 -> 256 k columns per workgroup, 2 -> 128 (for small gradients, where
+// twice the tiles means half the slices and half the atomic traffic on each address).
 
 struct GemmDwArgs {
   const float* dY; int lddy; int nout;    // [rows, nout]
-  const float* X; int ldx; int kin;       // [rows, kin]   (kin a multiple of 256 per grid.y block)
+  const float* X; int ldx; int kin;       // [rows, kin]   (kin a multiple of the 64 NTW columns of a grid.y block)
   int rows; int m_split;                  // m range per blockIdx.z (multiple of 16)
   float* dW; int lddw;                    // [nout, kin], pre-zeroed, accumulated atomically
   float* db;                              // nullable: [nout] bias gradient
 };
 
+template <int NTW>
 __global__ __launch_bounds__(512, 2) void gemm_dw_kernel(GemmDwArgs g) {
-  __shared__ __attribute__((aligned(1024))) float smem[GDW_LDS_BYTES / 4];
-  constexpr int ST = GDW_STAGE_FLOATS, A_FL = 16 * 128;
+  constexpr int KC = 64 * NTW;                       // k columns per workgroup
+  constexpr int ST = 16 * 128 + 16 * KC, A_FL = 16 * 128;
+  __shared__ __attribute__((aligned(1024))) float smem[3 * ST];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slab = wave & 3, half = wave >> 2;
-  const int n_blk = blockIdx.x * 128, k_blk = blockIdx.y * 256;
+  const int n_blk = blockIdx.x * 128, k_blk = blockIdx.y * KC;
   const int m_begin = blockIdx.z * g.m_split;
   const int m_end = min(g.rows, m_begin + g.m_split);
   if (m_begin >= m_end) return;
 
-  f32x16 acc[4];
+  f32x16 acc[NTW];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int ct = 0; ct < NTW; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 
@@ -50,9 +52,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_kernel(GemmDwArgs g) {
   const int a_slot = ((lane & 31) - 8 * (a_m & 1)) & 31;        // logical slot fetched into physical slot l & 31
   int a_col = n_blk + a_slot * 4;
   a_col = a_col + 3 < g.nout ? a_col : (g.nout >= 4 ? ((g.nout - 4) & ~3) : 0);   // clamp inside the row (masked later)
+  // B stage, NTW = 4: 16 rows x 1 KiB = 16 one-row pieces, two per wave (rows 2w, 2w + 1; lane l -> slot l);
+  //          NTW = 2: 16 rows x 512 B = 8 two-row pieces, one per wave (same shape as the A stage).
   int b_slot[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) b_slot[i] = (lane - 8 * ((wave * 2 + i) & 1)) & 63;
+  const int b2_slot = ((lane & 31) - 8 * (a_m & 1)) & 31;
   auto issue = [&](int chunk, int buf) {
     float* sA = smem + buf * ST;
     float* sB = sA + A_FL;
@@ -60,11 +65,15 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_kernel(GemmDwArgs g) {
     int ma = m0 + a_m;
     ma = ma < g.rows ? ma : g.rows - 1;
     lds_dma16(g.dY + (size_t)ma * g.lddy + a_col, sA + wave * 256);
+    if (NTW == 4) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int mb = m0 + wave * 2 + i;
-      mb = mb < g.rows ? mb : g.rows - 1;
-      lds_dma16(g.X + (size_t)mb * g.ldx + k_blk + b_slot[i] * 4, sB + (wave * 2 + i) * 256);
+      for (int i = 0; i < 2; ++i) {
+        int mb = m0 + wave * 2 + i;
+        mb = mb < g.rows ? mb : g.rows - 1;
+        lds_dma16(g.X + (size_t)mb * g.ldx + k_blk + b_slot[i] * 4, sB + (wave * 2 + i) * 256);
+      }
+    } else {
+      lds_dma16(g.X + (size_t)ma * g.ldx + k_blk + b2_slot * 4, sB + wave * 256);
     }
   };
 
@@ -77,8 +86,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_kernel(GemmDwArgs g) {
   if (nchunks > 1) issue(1, 1);
   int cur = 0;
   for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) __builtin_amdgcn_s_waitcnt(0x0F73);   // vmcnt(3)
-    else __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+    if (c + 1 < nchunks) __builtin_amdgcn_s_waitcnt(0x0F70 | (1 + NTW / 2));   // vmcnt(DMAs per chunk)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     if (c + 2 < nchunks) issue(c + 2, cur == 0 ? 2 : cur - 1);
     const float* sA = smem + cur * ST;
@@ -96,11 +105,11 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_kernel(GemmDwArgs g) {
       for (int s = 0; s < 8; ++s) bias_part += a[s];
     }
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const int b_off = (half * 128 + ct * 32 + fi + 32 * hk) & 255;
+    for (int ct = 0; ct < NTW; ++ct) {
+      const int b_off = (half * 32 * NTW + ct * 32 + fi + 32 * hk) & (KC - 1);
 #pragma unroll
       for (int s = 0; s < 8; ++s)
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], sB[(2 * s + hk) * 256 + b_off], acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], sB[(2 * s + hk) * KC + b_off], acc[ct], 0, 0, 0);
     }
     cur = cur == 2 ? 0 : cur + 1;
   }
@@ -111,8 +120,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dw_kernel(GemmDwArgs g) {
     const int n = n_blk + slab * 32 + G_ROW(r, lane);
     if (n < g.nout) {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const int k = k_blk + half * 128 + ct * 32 + c0;
+      for (int ct = 0; ct < NTW; ++ct) {
+        const int k = k_blk + half * 32 * NTW + ct * 32 + c0;
         if (k < g.kin) atomicAdd(g.dW + (size_t)n * g.lddw + k, acc[ct][r]);
       }
     }

@@ -283,18 +283,22 @@ int main() {
   }
   printf("--- weight-gradient kernel: dW[nout,kin] += dY^T X over M rows\n");
   {
-    auto run_dw = [&](int nout, int kin, int rows, int target) {
-      const int bx = (nout + 127) / 128, by = kin / 256;
+    auto run_dw = [&](int nout, int kin, int rows, int target, bool narrow = false) {
+      const int bx = (nout + 127) / 128, by = narrow ? kin / 128 : kin / 256;
       int splits = (target + bx * by - 1) / (bx * by);
       int m_split = ((rows + splits - 1) / splits + 15) / 16 * 16;
       splits = (rows + m_split - 1) / m_split;
       GemmDwArgs a{A, nout, nout, A + (size_t)E * 512, kin, kin, rows, m_split, C, kin, nullptr};
-      float ms = time_it([&] { hipLaunchKernelGGL(gemm_dw_kernel, dim3(bx, by, splits), dim3(512), 0, 0, a); }, 20);
+      float ms = narrow ? time_it([&] { hipLaunchKernelGGL(gemm_dw_kernel<2>, dim3(bx, by, splits), dim3(512), 0, 0, a); }, 20)
+                        : time_it([&] { hipLaunchKernelGGL(gemm_dw_kernel<4>, dim3(bx, by, splits), dim3(512), 0, 0, a); }, 20);
       char name[96];
-      snprintf(name, sizeof name, "dW %4dx%4d rows %d blocks %d (m %d)", nout, kin, rows, bx * by * splits, m_split);
+      snprintf(name, sizeof name, "dW %4dx%4d rows %d blocks %d (m %d)%s", nout, kin, rows, bx * by * splits, m_split,
+               narrow ? " narrow" : "");
       report(name, ms, 2.0 * rows * nout * kin);
     };
     for (int target : {128, 256, 384, 768}) run_dw(256, 256, M, target);
+    for (int target : {128, 256, 384, 768}) run_dw(256, 256, M, target, true);
+    run_dw(256, 256, E, 384, true);
     for (int target : {256, 384, 768}) run_dw(1024, 256, M, target);
     for (int target : {256, 384, 768}) run_dw(256, 1024, M, target);
     run_dw(768, 256, M, 384);
