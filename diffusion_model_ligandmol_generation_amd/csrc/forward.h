@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "../../include/ligdiff.h"
+#include "split_cache.h"
 
 // Byte offsets into the forward workspace (all 256-B aligned).
 struct FwdLayout {
@@ -23,8 +24,11 @@ struct FwdLayout {
   size_t t1_pre, ua, pen_pre, pg_pre, pz, pw;
   size_t pre_e[3], u_m[3], hc_pre[3], cw[3], dist[3], r1pre[3], hid_pre[3], u_h[3];
   size_t oproj[3], fproj[3], ffh_pre[3], lse[3], u_head, u_ph;
+  size_t wsplit, wsplit_bytes;      // split-bf16 copies of the GEMM weights (split-operand mode only, else 0 bytes)
   size_t total;
 };
+// Split-operand GEMM mode of the forward pass (process-wide; see ligdiff_set_split_gemm).
+bool split_gemm_enabled();
 void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags);
 
 // Measurement hook: the launch whose label equals `label` is bracketed by e0 / e1.
@@ -44,4 +48,4 @@ int run_time_rows(const float* const* w, const float* t, int n_rows, float* tf, 
 int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
                 const float* t, const int32_t* t_index_dev, const float* properties, int flags,
                 float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s,
-                FwdProbe* probe = nullptr);
+                FwdProbe* probe = nullptr, SplitCache* split = nullptr);

@@ -115,6 +115,34 @@ const WeightInfo* weight_table() {
 
 #include "launch.h"
 
+// ------------------------------------------------------------------ split-operand mode
+#include <atomic>
+static std::atomic<int> g_split_mode{-1};   // -1: not decided yet (environment), 0 / 1
+bool split_gemm_enabled() {
+  int m = g_split_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("LIGDIFF_GEMM_SPLIT");
+    m = (e != nullptr && e[0] != '\0' && e[0] != '0') ? 1 : 0;
+    g_split_mode.store(m, std::memory_order_relaxed);
+  }
+  return m != 0;
+}
+extern "C" int ligdiff_set_split_gemm(int enabled) {
+  const int prev = split_gemm_enabled() ? 1 : 0;
+  g_split_mode.store(enabled ? 1 : 0, std::memory_order_relaxed);
+  return prev;
+}
+// Bytes reserved for the split weight copies: 6 bytes per weight element plus room for blocks whose
+// rows are zero-extended to the 128 / 256 columns of a block (a full region falls back to the fp32 pipe).
+static size_t split_region_bytes() {
+  static const size_t bytes = [] {
+    size_t elems = 0;
+    for (int i = 0; i < W_CONS_0; ++i) elems += (size_t)weight_table()[i].numel;
+    return align_up(elems * 6 + elems * 6 / 4 + (2u << 20), 256);
+  }();
+  return bytes;
+}
+
 // ------------------------------------------------------------------ workspace layout
 void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
   memset(L, 0, sizeof *L);
@@ -160,6 +188,9 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
     }
     L->u_head = take(N * 512); L->u_ph = take((size_t)B * 256);
   }
+  L->wsplit = off;
+  L->wsplit_bytes = split_gemm_enabled() ? split_region_bytes() : 0;
+  off += L->wsplit_bytes;
   L->total = off;
 }
 
@@ -183,7 +214,8 @@ int run_time_rows(const float* const* w, const float* t, int n_rows, float* tf, 
 // ------------------------------------------------------------------ the forward pass
 int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
                 const float* t, const int32_t* t_index_dev, const float* properties, int flags,
-                float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s, FwdProbe* probe) {
+                float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s, FwdProbe* probe,
+                SplitCache* split) {
   const int N = (int)g->n_atoms, E = (int)g->n_edges, B = g->n_mols;
   // PB(label) ... PE(): brackets one launch with the probe's events when its label matches
   char lbl[48];
@@ -199,6 +231,19 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   };
   FwdLayout L;
   fwd_layout(&L, N, E, B, flags);
+  // split-operand mode: the caller's cache (kept over the calls of one sampling loop) or one for this call
+  SplitCache local_split;
+  struct SplitScope {
+    ~SplitScope() { g_split = nullptr; }
+  } split_scope;
+  if (L.wsplit_bytes > 0) {
+    SplitCache* c = split != nullptr ? split : &local_split;
+    if (c->base == nullptr) {
+      c->base = reinterpret_cast<uint16_t*>(ws + L.wsplit);
+      c->cap = L.wsplit_bytes / 2;
+    }
+    g_split = c;
+  }
   auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
   auto S = [&](size_t off) { return L.save ? reinterpret_cast<float*>(ws + off) : (float*)nullptr; };
   const int Bt = (int)L.Bt;

@@ -5,6 +5,8 @@
 
 #include "epilogues.h"
 #include "gemm3.h"
+#include "gemm4.h"
+#include "split_cache.h"
 
 // ------------------------------------------------------------------ launch helpers
 template <int NT, int WMODE, class AL, class EPI>
@@ -24,15 +26,60 @@ static inline bool use_cs() {
   static const bool v = getenv("LIGDIFF_GEMM_NOCS") == nullptr && getenv("LIGDIFF_GEMM_V1") == nullptr;
   return v;
 }
+// Split-operand mode (gemm4.h): while a cache is installed for the calling thread, the column-split
+// launches below convert each weight block they meet for the first time (one small launch on the
+// same stream) and run the bf16-pipe kernel; without a cache, or once its region is full, they run
+// the fp32-pipe kernel.
+static thread_local SplitCache* g_split = nullptr;
+
+template <int NTW>
+static inline bool split_blocks(const GemmCore& g, int nb, hipStream_t s, SplitW* out) {
+  SplitCache* c = g_split;
+  if (c == nullptr || c->base == nullptr || nb > 8) return false;
+  const int ncols = 64 * NTW;
+  const size_t need = (size_t)(g.K / G2_BK) * G4_CHUNK_ELEMS(NTW);
+  for (int b = 0; b < nb; ++b) {
+    const uint16_t* blk = nullptr;
+    for (int i = 0; i < c->n; ++i) {
+      const SplitCache::Entry& e = c->ent[i];
+      if (e.W == g.W[b] && e.ldw == g.ldw && e.K == g.K && e.n_valid == g.n_valid && e.ncols == ncols) {
+        blk = e.blk;
+        break;
+      }
+    }
+    if (blk == nullptr) {
+      if (c->n >= (int)(sizeof c->ent / sizeof c->ent[0]) || c->used + need > c->cap) return false;
+      uint16_t* dst = c->base + c->used;
+      hipLaunchKernelGGL(k_split_weight, dim3(ceil_div((g.K / G2_BK) * ncols, 256)), dim3(256), 0, s, g.W[b], g.ldw,
+                         g.n_valid, g.K, ncols, dst);
+      c->ent[c->n++] = SplitCache::Entry{g.W[b], g.ldw, g.K, g.n_valid, ncols, dst};
+      c->used += need;
+      blk = dst;
+    }
+    out->blk[b] = blk;
+  }
+  return true;
+}
+
 template <class AP, class EPI>
 static inline void launch_gemm_cs(const GemmCore& g, const AP& ap, const EPI& epi, int nb, hipStream_t s) {
   if (g.M <= 0) return;
+  SplitW sw;
+  if (g_split != nullptr && split_blocks<4>(g, nb, s, &sw)) {
+    hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 4, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, sw, ap, epi);
+    return;
+  }
   hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);
 }
 // 128-column blocks (n_valid <= 128 rows of W) on the eight-wave kernel with two accumulators per wave
 template <class AP, class EPI>
 static inline void launch_gemm_cs128(const GemmCore& g, const AP& ap, const EPI& epi, int nb, hipStream_t s) {
   if (g.M <= 0) return;
+  SplitW sw;
+  if (g_split != nullptr && split_blocks<2>(g, nb, s, &sw)) {
+    hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 2, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, sw, ap, epi);
+    return;
+  }
   hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);
 }
 template <int NT, class EPI>

@@ -379,17 +379,21 @@ static int sample_loop(const float* const* weights, const ligdiff_graph* graph, 
   a.t_index_dev = counter + 1; a.seed = seed; a.atom_offset = atom_offset; a.n_atoms = graph->n_atoms;
 
   const int base = LIGDIFF_FWD_T_BROADCAST | LIGDIFF_FWD_SKIP_PROP_HEAD | FWD_INTERNAL_TIME_GIVEN;
-  auto one_step = [&]() -> int {
-    hipLaunchKernelGGL(k_step_prologue, dim3(1), dim3(1024), 0, s, counter, tg, ddim ? 1 : -1);
+  SplitCache split;   // split-operand mode: weight blocks converted once for the whole loop
+  auto forwards = [&]() -> int {
     int r = run_forward(weights, graph, x, pos, nullptr, counter + 1, properties,
                         base | (properties ? LIGDIFF_FWD_PROPERTIES : 0), WF(L.eps_x), WF(L.eps_pos), nullptr,
-                        ws + L.fwd, s);
+                        ws + L.fwd, s, nullptr, &split);
     if (r) return r;
-    if (guided) {
+    if (guided)
       r = run_forward(weights, graph, x, pos, nullptr, counter + 1, nullptr, base, WF(L.eps_xu), WF(L.eps_pu), nullptr,
-                      ws + L.fwd, s);
-      if (r) return r;
-    }
+                      ws + L.fwd, s, nullptr, &split);
+    return r;
+  };
+  auto one_step = [&]() -> int {
+    hipLaunchKernelGGL(k_step_prologue, dim3(1), dim3(1024), 0, s, counter, tg, ddim ? 1 : -1);
+    int r = forwards();
+    if (r) return r;
     if (ddim) {
       const int64_t n = a.n_atoms * (LD_A + 3);
       hipLaunchKernelGGL(k_prediction_gate_guided, dim3(ceil_div(n, 256)), dim3(256), 0, s, a, graph->atom_mol, reject);
@@ -402,6 +406,13 @@ static int sample_loop(const float* const* weights, const ligdiff_graph* graph, 
   };
 
   hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, s, counter, ddim ? 0 : n_steps - 1);
+  if (use_graph && split_gemm_enabled()) {
+    // one forward outside the capture (its outputs are overwritten by the first step) so that the
+    // weight conversions are not part of the replayed graphs; delta 0 leaves the counter where it is
+    hipLaunchKernelGGL(k_step_prologue, dim3(1), dim3(1024), 0, s, counter, tg, 0);
+    rc = forwards();
+    if (rc) return rc;
+  }
   if (!use_graph) {
     for (int i = 0; i < n_steps; ++i) {
       rc = one_step();

@@ -4,10 +4,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <math.h>
 
 #include "../epilogues.h"
 #include "../gemm3.h"
 #include "../gemm_dw.h"
+#include "../gemm4.h"
 
 struct EpiNull {  // keeps the accumulators alive with one store per lane
   static constexpr int kStores = 0;
@@ -261,6 +263,79 @@ int main() {
       report("cs node_mlp2 M29696 K256 N256 LN", ms, 2.0 * M * 256 * 256);
       ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiNull>), dim3(232, 1), dim3(512), 0, 0, g2, ap, en); }, 20);
       report("cs           M29696 K256 N256 no epilogue", ms, 2.0 * M * 256 * 256);
+    }
+  }
+  printf("--- split-operand kernel (fp32 = 3 x bf16, six bf16 MFMA terms)\n");
+  {
+    uint16_t* Ws;
+    CK(hipMalloc(&Ws, (size_t)1024 * 1024 * 6));
+    auto split = [&](int K, int nb, int ldw, SplitW& sw) {
+      for (int b = 0; b < nb; ++b) {
+        uint16_t* dst = Ws + (size_t)b * (K / 16) * G4_CHUNK_ELEMS(4);
+        hipLaunchKernelGGL(k_split_weight, dim3((256 * (K / 16) + 255) / 256), dim3(256), 0, 0, W + (size_t)b * 256 * ldw, ldw, 256, K, 256, dst);
+        sw.blk[b] = dst;
+      }
+    };
+    EpiNull en{C};
+    {
+      GemmCore g = core(M, 256, 4, 256);
+      SplitW sw; memset(&sw, 0, sizeof sw);
+      split(256, 4, 256, sw);
+      APtrPlain ap{A, 256};
+      EpiBiasAct<8, ACT_GELU, false> e; memset(&e, 0, sizeof e);
+      e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = 1024; e.alpha = 1.f;
+      for (int i = 0; i < 4; ++i) e.bias[i] = bias + i * 256;
+      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_GELU, false>, 4, 2>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e); }, 20);
+      report("split NS2 ffn_up M29696 K256 N1024 GELU", ms, 2.0 * M * 256 * 1024);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_GELU, false>, 4, 3>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e); }, 20);
+      report("split NS3 ffn_up M29696 K256 N1024 GELU", ms, 2.0 * M * 256 * 1024);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiNull, 4, 2>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, en); }, 20);
+      report("split NS2        M29696 K256 N1024 no epi", ms, 2.0 * M * 256 * 1024);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiNull, 4, 3>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, en); }, 20);
+      report("split NS3        M29696 K256 N1024 no epi", ms, 2.0 * M * 256 * 1024);
+      // accuracy: plain store epilogue, both kernels against a double-precision host product
+      EpiBiasAct<8, ACT_NONE, false> e0; memcpy(&e0, &e, sizeof e);
+      for (int i = 0; i < 4; ++i) e0.bias[i] = nullptr;
+      std::vector<float> c32((size_t)256 * 1024), c16((size_t)256 * 1024);
+      hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiBiasAct<8, ACT_NONE, false>>), dim3(232, 4), dim3(512), 0, 0, g, ap, e0);
+      CK(hipMemcpy(c32.data(), C, c32.size() * 4, hipMemcpyDeviceToHost));
+      hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_NONE, false>, 4, 2>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e0);
+      CK(hipMemcpy(c16.data(), C, c16.size() * 4, hipMemcpyDeviceToHost));
+      double e32 = 0, e16 = 0, nrm = 0;
+      for (int m = 0; m < 256; ++m)
+        for (int n = 0; n < 1024; n += 7) {
+          double ref = 0;
+          for (int k = 0; k < 256; ++k) ref += (double)h[(size_t)m * 256 + k] * (double)h[(size_t)n * 256 + k];
+          e32 = fmax(e32, fabs(c32[(size_t)m * 1024 + n] - ref));
+          e16 = fmax(e16, fabs(c16[(size_t)m * 1024 + n] - ref));
+          nrm = fmax(nrm, fabs(ref));
+        }
+      printf("max |err| vs double: fp32 MFMA %.3e   split bf16 %.3e   (max |ref| %.3f)\n", e32, e16, nrm);
+    }
+    {
+      GemmCore g = core(M, 1024, 1, 1024);
+      SplitW sw; memset(&sw, 0, sizeof sw);
+      split(1024, 1, 1024, sw);
+      APtrPlain ap{A, 1024};
+      EpiGate<true> e{M, bias, C2, mod, 0, 0, mod, 256, 512, mol, C, C + (size_t)M * 256, nullptr};
+      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiGate<true>, 4, 2>), dim3(232, 1), dim3(512), 0, 0, g, sw, ap, e); }, 20);
+      report("split NS2 ffn_down M29696 K1024 N256 gate", ms, 2.0 * M * 1024 * 256);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiGate<true>, 4, 3>), dim3(232, 1), dim3(512), 0, 0, g, sw, ap, e); }, 20);
+      report("split NS3 ffn_down M29696 K1024 N256 gate", ms, 2.0 * M * 1024 * 256);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiNull, 4, 3>), dim3(232, 1), dim3(512), 0, 0, g, sw, ap, en); }, 20);
+      report("split NS3          M29696 K1024 N256 no epi", ms, 2.0 * M * 1024 * 256);
+    }
+    {
+      GemmCore g = core(E, 256, 1, 256);
+      SplitW sw; memset(&sw, 0, sizeof sw);
+      split(256, 1, 256, sw);
+      APtrPlain ap{A, 256};
+      EpiLN<ACT_NONE, ACT_NONE, false> e; memset(&e, 0, sizeof e);
+      e.M = E; e.bias[0] = bias; e.gamma[0] = bias + 256; e.beta[0] = bias + 512; e.eps = 1e-5f; e.C = C; e.ldc = 256;
+      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>, 4, 2>), dim3(496, 1), dim3(512), 0, 0, g, sw, ap, e); }, 20);
+      report("split NS2 edge_mlp2 M63488 K256 N256 LN", ms, 2.0 * E * 256 * 256);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>, 4, 3>), dim3(496, 1), dim3(512), 0, 0, g, sw, ap, e); }, 20);
+      report("split NS3 edge_mlp2 M63488 K256 N256 LN", ms, 2.0 * E * 256 * 256);
     }
   }
   printf("--- main-loop ablation (ffn_up shape, by=4; and ffn_down shape K=1024 by=1)\n");

@@ -21,6 +21,59 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, int iters) {
   if (s == 123.456f) out[0] = s;
 }
 
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x16_bf16 from registers only; SAME = 1: six instructions in a row on one
+// accumulator (the order the split-operand GEMM issues them), 0: round-robin over four accumulators.
+template <int SAME>
+__global__ __launch_bounds__(256) void k_mfma_bf16(float* out, int iters) {
+  f32x16 acc[4];
+  for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  u32x4 au = {threadIdx.x, 1u, 2u, 3u}, bu = {blockIdx.x, 5u, 6u, 7u};
+  const bf16x8 a = __builtin_bit_cast(bf16x8, au), b = __builtin_bit_cast(bf16x8, bu);
+  for (int i = 0; i < iters; ++i) {
+    if (SAME) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 16; ++r) s += acc[t][r];
+  if (s == 123.456f) out[0] = s;
+}
+
+template <int SAME>
+static void run_bf16(float* d) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 4000;
+  for (int wpb = 1; wpb <= 4; wpb *= 2) {
+    const int blocks = 256 * wpb;
+    hipLaunchKernelGGL(k_mfma_bf16<SAME>, dim3(blocks), dim3(256), 0, 0, d, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_mfma_bf16<SAME>, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)blocks * 4 * iters * 24 * 32768.0;
+    printf("bf16 32x32x16 %s, waves/SIMD %d: %.3f ms  %.1f TFLOP/s (= %.1f fp32-equivalent at six terms)\n",
+           SAME ? "six in a row per accumulator" : "round-robin", wpb, ms, flop / (ms * 1e-3) / 1e12,
+           flop / 6 / (ms * 1e-3) / 1e12);
+  }
+}
+
 int main() {
   float* d;
   hipMalloc(&d, 4);
@@ -40,5 +93,7 @@ int main() {
     const double flop = (double)blocks * 4 * iters * 32 * 4096.0;
     printf("waves/SIMD %d: %.3f ms  %.1f TFLOP/s\n", wpb, ms, flop / (ms * 1e-3) / 1e12);
   }
+  run_bf16<0>(d);
+  run_bf16<1>(d);
   return 0;
 }

@@ -120,6 +120,12 @@ class ScoreNetworkEngine:
                 return True
         return False
 
+    def set_split_gemm(self, enabled):
+        """Switch the library's forward GEMMs between the fp32 matrix pipe (False, default) and the
+        three-way bf16 operand split on the bf16 pipe (True); returns the previous setting.
+        Process-wide (include/ligdiff.h: ligdiff_set_split_gemm)."""
+        return bool(self.lib.ligdiff_set_split_gemm(1 if enabled else 0))
+
     def workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)

@@ -186,6 +186,17 @@ int ligdiff_loss_partial(const ligdiff_loss_args* args, float* sums8, void* stre
 int ligdiff_loss_finish(const ligdiff_loss_args* args, const float* sums8, float upstream,
                         float* losses32, float* d_atom, float* d_pos, float* d_prop, void* stream);
 
+/* Process-wide switch for how the forward pass (and the sampling loops built on it) multiplies its
+ * fp32 matrices; returns the previous setting.  0 (default, or LIGDIFF_GEMM_SPLIT unset in the
+ * environment): v_mfma_f32_32x32x2_f32.  1: each fp32 operand is the exact sum of three bf16 numbers
+ * and six of the nine partial products run on the bf16 matrix pipe with fp32 accumulation; the three
+ * dropped products are below 2^-23 of the product, i.e. one fp32 rounding, so results agree with mode
+ * 0 to fp32 rounding error.  The *_workspace_bytes functions depend on the setting (mode 1 keeps
+ * split copies of the weights, about 40 MB, in the workspace): size the workspace after switching,
+ * and do not switch while a call is running.  No counterpart in the reference (torch.nn.Linear in
+ * fp32 throughout, model1.py:60-114, :255-302). */
+int ligdiff_set_split_gemm(int enabled);
+
 /* Byte offsets, inside the workspace of a completed ligdiff_forward call with the same sizes and
  * flags, of the final hidden state h [n_atoms,256] (model1.py:738) and of pos + pos_updates
  * [n_atoms,3] (model1.py:752): the two inputs of the consistency module. */
