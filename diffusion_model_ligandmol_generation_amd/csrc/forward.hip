@@ -401,8 +401,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         // E = 2 x atoms rows already give two 4-wave workgroups per CU; the eight-wave form measured
         // slower here (its dot-product head needs the mailbox exchange and a barrier)
         if (use_gemm2()) {
-          hipLaunchKernelGGL((gemm_rows2_kernel<4, APtrPlain, EpiCoord>), dim3(ceil_div(E, G_BM), 1), dim3(256), 0, s, gc,
-                             APtrPlain{F(L.msg[l]), 256}, e);
+          launch_gemm_rows128(gc, APtrPlain{F(L.msg[l]), 256}, e, 1, s);
         } else {
           ALoadPlain alc{F(L.msg[l]), 256, E, 256};
           launch_gemm<4, W_ALIGNED>(gc, alc, e, 1, s);

@@ -27,7 +27,7 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // bf16 elements of one K chunk of a column block of 64 NTW columns
-#define G4_CHUNK_ELEMS(NTW) (3 * 2 * 64 * (NTW) * 8)
+#define G4_CHUNK_ELEMS(NTW) (3 * 2 * 64 * (NTW) * 8)   // = 48 bf16 per column
 
 struct SplitW {
   const uint16_t* blk[8];   // blk[by]: [K/16 chunks][3 planes][2 lane halves][64 NTW columns][8] bf16
@@ -84,19 +84,32 @@ static __global__ void k_split_weight(const float* __restrict__ W, int ldw, int 
   }
 }
 
-template <class AP, class EPI, int NTW = 4, int NS = 2>
-__global__ __launch_bounds__(512, 2) void gemm_cs_split_kernel(GemmCore g, SplitW sw, AP ap, EPI epi) {
+// Stage buffers: W chunks (6 NTW KiB, L2-resident) are double-buffered; A chunks (8 KiB) have NSA
+// buffers.  With NSA = 3 a wave issues its W pieces of chunk kc + 1 and THEN its A piece of chunk
+// kc + 2, so "all but the newest DMA done" (s_waitcnt vmcnt(1)) is exactly "chunk kc + 1 landed";
+// measured on the FFN shapes this is 2-3 % slower than plain double buffering (NSA = 2, the default):
+// with four waves per SIMD the DMA latency is already covered.
+//
+// WAVES = 8: the column-split form above (EPI::cs).  WAVES = 4: wave = 32-row slab x ALL 32 NTW columns of
+// the block, the ownership of gemm_rows2_kernel, for epilogues that need whole rows in one wave
+// (EPI::operator()); 256 threads, no mailbox.
+template <class AP, class EPI, int NTW = 4, int NSA = 2, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES, 2) void gemm_cs_split_kernel(GemmCore g, SplitW sw, AP ap, EPI epi) {
+  constexpr int NCOL = (WAVES == 8) ? 64 * NTW : 32 * NTW;   // columns of the block
   constexpr int A_FL = 128 * G2_ROWF;                 // fp32 A stage: 128 rows x 16
-  constexpr int B_FL = G4_CHUNK_ELEMS(NTW) / 2;       // split W stage, in floats
-  constexpr int ST = A_FL + B_FL;
-  constexpr int PIECES = B_FL / 256;                  // 1-KiB DMA pieces of the W stage (6 NTW)
-  constexpr int PW = (PIECES + 7) / 8;                // per wave (the last waves repeat the last piece)
-  constexpr int PLANE_B = 2 * 64 * NTW * 16;          // bytes per plane
-  __shared__ __attribute__((aligned(1024))) float smem4[NS * ST + 4 * 256];
+  constexpr int CHUNK = 3 * 2 * NCOL * 8;             // bf16 elements of one split W chunk
+  constexpr int B_FL = CHUNK / 2;                     // split W stage, in floats
+  constexpr int PIECES = B_FL / 256;                  // 1-KiB DMA pieces of the W stage
+  constexpr int PW = (PIECES + WAVES - 1) / WAVES;    // per wave (the last waves repeat the last piece)
+  constexpr int PA = 8 / WAVES;                       // A pieces (16 rows each) per wave
+  constexpr int PLANE_B = 2 * NCOL * 16;              // bytes per plane
+  __shared__ __attribute__((aligned(1024))) float smem4[NSA * A_FL + 2 * B_FL + (WAVES == 8 ? 4 * 256 : 0)];
+  float* const sA_base = smem4;
+  float* const sB_base = smem4 + NSA * A_FL;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int slab = wave & 3, half = wave >> 2;
+  const int slab = wave & 3, half = (WAVES == 8) ? wave >> 2 : 0;
   const int by = blockIdx.y;
   const int row_blk = blockIdx.x * 128;
 
@@ -108,8 +121,12 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_split_kernel(GemmCore g, Split
 
   const int pr = lane >> 2, ps = lane & 3;
   const int lslot = ps ^ ((pr >> 2) & 3);
-  int a_row = row_blk + wave * 16 + pr;
-  a_row = a_row < g.M ? a_row : g.M - 1;
+  int a_row[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int r = row_blk + (wave * PA + i) * 16 + pr;
+    a_row[i] = r < g.M ? r : g.M - 1;
+  }
   const uint16_t* bsrc[PW];
   int bdst[PW];
 #pragma unroll
@@ -119,32 +136,35 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_split_kernel(GemmCore g, Split
     bsrc[i] = sw.blk[by] + p * 512 + lane * 8;
     bdst[i] = p * 256;
   }
-  auto issue = [&](int kc, int buf) {
-    float* sA = smem4 + buf * ST;
-    float* sB = sA + A_FL;
-    lds_dma16(ap.ptr(a_row, kc * G2_BK + lslot * 4), sA + wave * 256);
+  auto issue_a = [&](int kc, int buf) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      lds_dma16(ap.ptr(a_row[i], kc * G2_BK + lslot * 4), sA_base + buf * A_FL + (wave * PA + i) * 256);
+  };
+  auto issue_b = [&](int kc, int buf) {
 #pragma unroll
     for (int i = 0; i < PW; ++i)
-      lds_dma16(reinterpret_cast<const float*>(bsrc[i] + (size_t)kc * G4_CHUNK_ELEMS(NTW)), sB + bdst[i]);
+      lds_dma16(reinterpret_cast<const float*>(bsrc[i] + (size_t)kc * CHUNK),
+                sB_base + buf * B_FL + bdst[i]);
   };
 
   const int nk = g.K / G2_BK;
   const int fi = lane & 31, hk = lane >> 5;
   const int swz = (fi >> 2) & 3;
   const int off0 = ((0 * 2 + hk) ^ swz) * 4, off1 = ((1 * 2 + hk) ^ swz) * 4;
-  const int b_lane = (hk * 64 * NTW + half * 32 * NTW + fi) * 16;     // byte offset inside a plane
-#pragma unroll
-  for (int i = 0; i < NS - 1; ++i)
-    if (i < nk) issue(i, i);
-  int cur = 0;
+  const int b_lane = (hk * NCOL + half * 32 * NTW + fi) * 16;     // byte offset inside a plane
+  issue_a(0, 0);
+  issue_b(0, 0);
+  if (NSA == 3 && nk > 1) issue_a(1, 1);
+  int cur_a = 0;
   for (int kc = 0; kc < nk; ++kc) {
-    // this wave's DMAs of chunk kc are done (newer chunks may stay in flight), then join
-    if (NS > 2 && kc + NS - 2 < nk) wait_vm_count<(NS - 2) * (1 + PW)>();
+    if (NSA == 3 && kc + 1 < nk) wait_vm_count<PA>();
     else wait_vm_count<0>();
     __builtin_amdgcn_s_barrier();
-    if (kc + NS - 1 < nk) issue(kc + NS - 1, cur == 0 ? NS - 1 : cur - 1);
-    const float* sA = smem4 + cur * ST;
-    const char* sB = reinterpret_cast<const char*>(sA + A_FL) + b_lane;
+    if (kc + 1 < nk) issue_b(kc + 1, (kc + 1) & 1);
+    if (kc + NSA - 1 < nk) issue_a(kc + NSA - 1, cur_a == 0 ? NSA - 1 : cur_a - 1);
+    const float* sA = sA_base + cur_a * A_FL;
+    const char* sB = reinterpret_cast<const char*>(sB_base + (kc & 1) * B_FL) + b_lane;
     const float* arow = sA + (slab * 32 + fi) * G2_ROWF;
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + off0);
     const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + off1);
@@ -184,8 +204,12 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_split_kernel(GemmCore g, Split
       acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc[ct], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    cur = cur == NS - 1 ? 0 : cur + 1;
+    cur_a = cur_a == NSA - 1 ? 0 : cur_a + 1;
   }
-  HalfMailbox mb{smem4 + NS * ST, wave, lane};
-  epi.cs(acc, row_blk + slab * 32, by, half, lane, mb);
+  if constexpr (WAVES == 8) {
+    HalfMailbox mb{smem4 + NSA * A_FL + 2 * B_FL, wave, lane};
+    epi.cs(acc, row_blk + slab * 32, by, half, lane, mb);
+  } else {
+    epi(acc, row_blk + wave * 32, by, lane);
+  }
 }

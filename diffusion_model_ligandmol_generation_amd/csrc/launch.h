@@ -66,10 +66,22 @@ static inline void launch_gemm_cs(const GemmCore& g, const AP& ap, const EPI& ep
   if (g.M <= 0) return;
   SplitW sw;
   if (g_split != nullptr && split_blocks<4>(g, nb, s, &sw)) {
-    hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 4, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, sw, ap, epi);
+    hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 4>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, sw, ap, epi);
     return;
   }
   hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);
+}
+// Four-wave row-slab launch for epilogues that need whole 128-column rows in one wave (operator() form):
+// the split-operand kernel when a cache is installed, else the fp32 LDS-DMA kernel of gemm2.h.
+template <class AP, class EPI>
+static inline void launch_gemm_rows128(const GemmCore& g, const AP& ap, const EPI& epi, int nb, hipStream_t s) {
+  if (g.M <= 0) return;
+  SplitW sw;
+  if (g_split != nullptr && split_blocks<2>(g, nb, s, &sw)) {
+    hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 4, 2, 4>), dim3(ceil_div(g.M, 128), nb), dim3(256), 0, s, g, sw, ap, epi);
+    return;
+  }
+  hipLaunchKernelGGL((gemm_rows2_kernel<4, AP, EPI>), dim3(ceil_div(g.M, G_BM), nb), dim3(256), 0, s, g, ap, epi);
 }
 // 128-column blocks (n_valid <= 128 rows of W) on the eight-wave kernel with two accumulators per wave
 template <class AP, class EPI>
@@ -77,7 +89,7 @@ static inline void launch_gemm_cs128(const GemmCore& g, const AP& ap, const EPI&
   if (g.M <= 0) return;
   SplitW sw;
   if (g_split != nullptr && split_blocks<2>(g, nb, s, &sw)) {
-    hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 2, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, sw, ap, epi);
+    hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, sw, ap, epi);
     return;
   }
   hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);

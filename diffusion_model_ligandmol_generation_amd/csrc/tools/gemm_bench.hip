@@ -285,21 +285,26 @@ int main() {
       EpiBiasAct<8, ACT_GELU, false> e; memset(&e, 0, sizeof e);
       e.M = M; e.n_valid = 256; e.col_block = 256; e.C = C; e.ldc = 1024; e.alpha = 1.f;
       for (int i = 0; i < 4; ++i) e.bias[i] = bias + i * 256;
-      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_GELU, false>, 4, 2>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e); }, 20);
-      report("split NS2 ffn_up M29696 K256 N1024 GELU", ms, 2.0 * M * 256 * 1024);
-      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_GELU, false>, 4, 3>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e); }, 20);
-      report("split NS3 ffn_up M29696 K256 N1024 GELU", ms, 2.0 * M * 256 * 1024);
-      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiNull, 4, 2>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, en); }, 20);
-      report("split NS2        M29696 K256 N1024 no epi", ms, 2.0 * M * 256 * 1024);
-      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiNull, 4, 3>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, en); }, 20);
-      report("split NS3        M29696 K256 N1024 no epi", ms, 2.0 * M * 256 * 1024);
+      float ms;
+      for (int rep = 0; rep < 4; ++rep) {
+        ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_GELU, false>, 4>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e); }, 50);
+        report("split ffn_up M29696 K256 N1024 GELU", ms, 2.0 * M * 256 * 1024);
+        ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiNull, 4, 3>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, en); }, 50);
+        report("split A3     M29696 K256 N1024 no epi", ms, 2.0 * M * 256 * 1024);
+        ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiNull, 4, 2>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, en); }, 50);
+        report("split A2     M29696 K256 N1024 no epi", ms, 2.0 * M * 256 * 1024);
+        ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_GELU, false>, 4, 2>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e); }, 50);
+        report("split A2 ffn_up M29696 K256 N1024 GELU", ms, 2.0 * M * 256 * 1024);
+        ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiNull>), dim3(232, 4), dim3(512), 0, 0, g, ap, en); }, 50);
+        report("fp32         M29696 K256 N1024 no epi", ms, 2.0 * M * 256 * 1024);
+      }
       // accuracy: plain store epilogue, both kernels against a double-precision host product
       EpiBiasAct<8, ACT_NONE, false> e0; memcpy(&e0, &e, sizeof e);
       for (int i = 0; i < 4; ++i) e0.bias[i] = nullptr;
       std::vector<float> c32((size_t)256 * 1024), c16((size_t)256 * 1024);
       hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiBiasAct<8, ACT_NONE, false>>), dim3(232, 4), dim3(512), 0, 0, g, ap, e0);
       CK(hipMemcpy(c32.data(), C, c32.size() * 4, hipMemcpyDeviceToHost));
-      hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_NONE, false>, 4, 2>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e0);
+      hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_NONE, false>, 4>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e0);
       CK(hipMemcpy(c16.data(), C, c16.size() * 4, hipMemcpyDeviceToHost));
       double e32 = 0, e16 = 0, nrm = 0;
       for (int m = 0; m < 256; ++m)
@@ -318,12 +323,10 @@ int main() {
       split(1024, 1, 1024, sw);
       APtrPlain ap{A, 1024};
       EpiGate<true> e{M, bias, C2, mod, 0, 0, mod, 256, 512, mol, C, C + (size_t)M * 256, nullptr};
-      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiGate<true>, 4, 2>), dim3(232, 1), dim3(512), 0, 0, g, sw, ap, e); }, 20);
-      report("split NS2 ffn_down M29696 K1024 N256 gate", ms, 2.0 * M * 1024 * 256);
-      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiGate<true>, 4, 3>), dim3(232, 1), dim3(512), 0, 0, g, sw, ap, e); }, 20);
-      report("split NS3 ffn_down M29696 K1024 N256 gate", ms, 2.0 * M * 1024 * 256);
-      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiNull, 4, 3>), dim3(232, 1), dim3(512), 0, 0, g, sw, ap, en); }, 20);
-      report("split NS3          M29696 K1024 N256 no epi", ms, 2.0 * M * 1024 * 256);
+      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiGate<true>, 4>), dim3(232, 1), dim3(512), 0, 0, g, sw, ap, e); }, 50);
+      report("split ffn_down M29696 K1024 N256 gate", ms, 2.0 * M * 1024 * 256);
+      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiNull, 4>), dim3(232, 1), dim3(512), 0, 0, g, sw, ap, en); }, 20);
+      report("split          M29696 K1024 N256 no epi", ms, 2.0 * M * 1024 * 256);
     }
     {
       GemmCore g = core(E, 256, 1, 256);
@@ -332,10 +335,8 @@ int main() {
       APtrPlain ap{A, 256};
       EpiLN<ACT_NONE, ACT_NONE, false> e; memset(&e, 0, sizeof e);
       e.M = E; e.bias[0] = bias; e.gamma[0] = bias + 256; e.beta[0] = bias + 512; e.eps = 1e-5f; e.C = C; e.ldc = 256;
-      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>, 4, 2>), dim3(496, 1), dim3(512), 0, 0, g, sw, ap, e); }, 20);
-      report("split NS2 edge_mlp2 M63488 K256 N256 LN", ms, 2.0 * E * 256 * 256);
-      ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>, 4, 3>), dim3(496, 1), dim3(512), 0, 0, g, sw, ap, e); }, 20);
-      report("split NS3 edge_mlp2 M63488 K256 N256 LN", ms, 2.0 * E * 256 * 256);
+      float ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, false>, 4>), dim3(496, 1), dim3(512), 0, 0, g, sw, ap, e); }, 50);
+      report("split edge_mlp2 M63488 K256 N256 LN", ms, 2.0 * E * 256 * 256);
     }
   }
   printf("--- main-loop ablation (ffn_up shape, by=4; and ffn_down shape K=1024 by=1)\n");
