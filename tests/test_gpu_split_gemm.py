@@ -1,0 +1,136 @@
+"""GPU: the library's split-operand GEMM mode (fp32 operands as three bf16 terms, six products on
+the bf16 matrix pipe, fp32 accumulation) against the same fixtures and oracle as the default
+fp32-pipe mode, at the same tolerance (fp32 rtol 1e-4), and against the default mode itself."""
+import contextlib
+import copy
+
+import pytest
+import torch
+
+import oracle
+from conftest import golden, seed0_model, seed0_state_dict
+from test_gpu_forward import ATOL, RTOL, Bag, _random_batch, _to
+from test_gpu_sampler import SeededNoise, _gen
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def split_gemm(enabled=True):
+    from diffusion_model_ligandmol_generation_amd import _lib
+    lib = _lib.load()
+    prev = lib.ligdiff_set_split_gemm(1 if enabled else 0)
+    try:
+        yield
+    finally:
+        lib.ligdiff_set_split_gemm(prev)
+
+
+def test_switch_returns_previous_setting_and_sizes_the_workspace():
+    from diffusion_model_ligandmol_generation_amd import _lib
+    lib = _lib.load()
+    with split_gemm(False):
+        assert lib.ligdiff_set_split_gemm(1) == 0
+        assert lib.ligdiff_set_split_gemm(1) == 1
+        on = lib.ligdiff_forward_workspace_bytes(290, 620, 10, 0)
+        on_s = lib.ligdiff_ddpm_sample_workspace_bytes(290, 620, 10, 0, 50)
+        assert lib.ligdiff_set_split_gemm(0) == 1
+        off = lib.ligdiff_forward_workspace_bytes(290, 620, 10, 0)
+        off_s = lib.ligdiff_ddpm_sample_workspace_bytes(290, 620, 10, 0, 50)
+    # the split copies of the weights: 6 bytes per GEMM weight element and some slack
+    n_w = sum(lib.ligdiff_weight_numel(i) for i in range(lib.ligdiff_weight_count()))
+    assert 4 * n_w < on - off < 12 * n_w and on_s - off_s == on - off
+
+
+@pytest.mark.parametrize("name,tkey,use_props,cfg", [
+    ("int_noprop", "t_int", False, False), ("flt_noprop", "t_flt", False, False),
+    ("int_prop", "t_int", True, False), ("int_cfgnull", "t_int", True, True)])
+def test_split_forward_matches_reference_fixture(name, tkey, use_props, cfg):
+    f = golden("forward.npz")
+    m = copy.deepcopy(seed0_model()).cuda().eval()
+    x, pos, ei, b = _to(f, ("x", "pos", "edge_index", "batch"))
+    t = torch.from_numpy(f[tkey]).cuda()
+    props = torch.from_numpy(f["props"]).cuda() if use_props else None
+    with torch.no_grad(), split_gemm():
+        a, p, r, _ = m(Bag(x=x, pos=pos, edge_index=ei, batch=b), t, props, cfg)
+    torch.testing.assert_close(a.cpu(), torch.from_numpy(f[f"{name}_atom"]), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(p.cpu(), torch.from_numpy(f[f"{name}_pos"]), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(r.cpu(), torch.from_numpy(f[f"{name}_prop"]), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("sizes,fc", [([29] * 64, False), ([5, 6, 15, 16, 2, 31, 33, 64], False),
+                                      ([65, 100, 40], True), ([3], False)])
+def test_split_forward_matches_oracle_and_default_mode(sizes, fc):
+    max_atoms = 128 if max(sizes) > 100 or fc else 100
+    m = copy.deepcopy(seed0_model(max_atoms=max_atoms)).cuda().eval()
+    sd = seed0_state_dict(max_atoms=max_atoms)
+    c = _random_batch(sizes, 99, fc)
+    B = len(sizes)
+    t = torch.arange(B, dtype=torch.float32) * 37.0 % 1000
+    x, pos, ei, b = (torch.from_numpy(c[k]) for k in ("x", "pos", "edge_index", "batch"))
+    data = Bag(x=x.cuda(), pos=pos.cuda(), edge_index=ei.cuda(), batch=b.cuda())
+    with torch.no_grad():
+        ea, ep, er = oracle.score_network_forward(sd, x, pos, ei, b, t, None, max_atoms=max_atoms, pad_to_max_atoms=False)
+        with split_gemm():
+            a, p, r, _ = m(data, t.cuda())
+        with split_gemm(False):
+            a0, p0, r0, _ = m(data, t.cuda())
+    for got, want in ((a, ea), (p, ep), (r, er)):
+        torch.testing.assert_close(got.cpu(), want, rtol=RTOL, atol=ATOL)
+    # the two modes differ by fp32 rounding only: an order of magnitude inside the tolerance above
+    for got, ref in ((a, a0), (p, p0), (r, r0)):
+        assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert not (torch.equal(a, a0) and torch.equal(p, p0)), "split mode did not take another path"
+
+
+@pytest.mark.parametrize("tag", ["ddpm_T50", "ddpm_T50_cfg"])
+def test_split_ddpm_trajectory_matches_reference(tag):
+    s = golden("sampler.npz")
+    T, n, _, seed, wp = [int(v) for v in s[tag + "_meta"]]
+    gen = _gen(T)
+    noise = SeededNoise(seed, n, T)
+    tp = torch.from_numpy(s[tag + "_props"]) if wp else None
+    with split_gemm():
+        x, pos, _, _ = gen.sample_batch([n], tp, 2.0, 0.9, noise=noise)
+    fx, fp = torch.from_numpy(s[tag + "_final_x"]), torch.from_numpy(s[tag + "_final_pos"])
+    torch.testing.assert_close(x.cpu(), fx, rtol=1e-3, atol=1e-3 * float(fx.abs().max()))
+    torch.testing.assert_close(pos.cpu(), fp, rtol=1e-3, atol=1e-3 * float(fp.abs().max()))
+
+
+def test_split_library_loop_graph_replay_host_loop_and_shards_agree_bitwise():
+    """The weight conversion runs once, outside the captured graphs; neither it nor the sharding may
+    change a bit of the result."""
+    gen = _gen(T=20)
+    sizes = [9, 17, 29, 5]
+    with split_gemm():
+        xa, pa, _, _ = gen.sample_batch(sizes, None, 1.0, 1.0, seed=11, use_graph=True)
+        xb, pb, _, _ = gen.sample_batch(sizes, None, 1.0, 1.0, seed=11, use_graph=False)
+        x1, p1, _, _ = gen.sample_batch(sizes[:2], None, 1.0, 1.0, seed=11, atom_offset=0)
+        x2, p2, _, _ = gen.sample_batch(sizes[2:], None, 1.0, 1.0, seed=11, atom_offset=sum(sizes[:2]))
+    with split_gemm(False):
+        xf, pf, _, _ = gen.sample_batch(sizes, None, 1.0, 1.0, seed=11, use_graph=True)
+    assert torch.equal(xa, xb) and torch.equal(pa, pb)
+    assert torch.equal(torch.cat([x1, x2]), xa) and torch.equal(torch.cat([p1, p2]), pa)
+    assert torch.isfinite(xa).all() and torch.isfinite(pa).all()
+    # 20 steps in the two modes: same trajectory up to accumulated fp32 rounding
+    assert float((xa - xf).abs().max()) < 1e-3 * float(xf.abs().max())
+    assert float((pa - pf).abs().max()) < 1e-3 * float(pf.abs().max())
+
+
+def test_split_training_step_gradients_match_default_mode():
+    """Forward in split mode, backward on the fp32 pipe: losses and gradients stay within the
+    training tolerance of the default mode."""
+    c = _random_batch([12, 29, 7, 18], 5)
+    x, pos, ei, b = (torch.from_numpy(c[k]).cuda() for k in ("x", "pos", "edge_index", "batch"))
+    t = torch.tensor([10.0, 500.0, 900.0, 3.0], device="cuda")
+    grads = {}
+    for mode in (False, True):
+        m = copy.deepcopy(seed0_model()).cuda().eval()
+        with split_gemm(mode):
+            a, p, r, _ = m(Bag(x=x, pos=pos, edge_index=ei, batch=b), t)
+            ((a ** 2).mean() + (p ** 2).mean() + (r ** 2).mean()).backward()
+        grads[mode] = {n: q.grad.detach().clone() for n, q in m.named_parameters() if q.grad is not None}
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 50
+    for n, g0 in grads[False].items():
+        scale = float(g0.abs().max())
+        assert float((grads[True][n] - g0).abs().max()) <= 1e-4 * scale + 1e-9, n
