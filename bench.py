@@ -32,6 +32,7 @@ PEAK_HBM_GBS = 8000.0            # MI355X HBM3E peak
 # the gfx950 correction for wide reads); the counters cannot be read from inside this process, so
 # these are the figures of the committed profile (profiles/r1_b_pmc_summary.csv), not live ones.
 FFN_UP_TRAFFIC_BYTES = 2 * 43616.9e3 * 1.024 + 118784.0e3 * 1.024
+FFN_UP_SPLIT_TRAFFIC_BYTES = 2 * 49581.6e3 * 1.024 + 118784.0e3 * 1.024   # profiles/r1_e_split_pmc_summary.csv
 AGGREGATE_TRAFFIC_BYTES = 2 * 35435.5e3 * 1.024 + 30404.5e3 * 1.024
 
 
@@ -197,7 +198,7 @@ def main():
             ach = 6.0 * flops / (ms * 1e-3) / 1e12
             return {"kernel": "gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8,GELU>> (dit*.ffn_up, M=29696 K=256 N=1024)",
                     "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms,
+                    "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": FFN_UP_SPLIT_TRAFFIC_BYTES, "avg_launch_ms": ms,
                     "fp32_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
                     "note": "achieved counts the six bf16 MFMA products issued per fp32 product"}
         roofline = ffn_up_roofline(split_mode)
