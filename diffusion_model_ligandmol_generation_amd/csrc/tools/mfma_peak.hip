@@ -84,6 +84,49 @@ __global__ __launch_bounds__(256) void k_mfma_bf16_toggle(float* out, int iters)
   if (s == 123.456f) out[0] = s;
 }
 
+__global__ __launch_bounds__(256) void k_mfma_f32_toggle(float* out, int iters) {
+  f32x16 acc[4];
+  for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float a[8], b[8];
+  unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  for (int j = 0; j < 8; ++j) {
+    h = h * 1664525u + 1013904223u; a[j] = __uint_as_float((h & 0x807fffffu) | 0x3f000000u);
+    h = h * 1664525u + 1013904223u; b[j] = __uint_as_float((h & 0x807fffffu) | 0x3f000000u);
+  }
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[(j + t) & 7], acc[t], 0, 0, 0);
+    if ((i & 255) == 255)
+      for (int t = 0; t < 4; ++t)
+        for (int r = 0; r < 16; ++r) acc[t][r] *= 1e-3f;
+  }
+  float s = 0.f;
+  for (int t = 0; t < 4; ++t)
+    for (int r = 0; r < 16; ++r) s += acc[t][r];
+  if (s == 123.456f) out[0] = s;
+}
+
+static void run_f32_toggle(float* d) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int iters : {2000, 20000}) {
+    const int blocks = 256 * 4;
+    hipLaunchKernelGGL(k_mfma_f32_toggle, dim3(blocks), dim3(256), 0, 0, d, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_mfma_f32_toggle, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)blocks * 4 * iters * 32 * 4096.0;
+    printf("f32 32x32x2 varying operands, waves/SIMD 4, %.1f ms run: %.1f TFLOP/s\n", ms, flop / (ms * 1e-3) / 1e12);
+  }
+}
+
 static void run_bf16_toggle(float* d) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -147,5 +190,6 @@ int main() {
   run_bf16<0>(d);
   run_bf16<1>(d);
   run_bf16_toggle(d);
+  run_f32_toggle(d);
   return 0;
 }
