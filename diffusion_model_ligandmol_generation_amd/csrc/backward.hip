@@ -17,7 +17,7 @@ struct BwdLayout {
   size_t dxa, n256b, n256c, n256d, n512, n768, n1024, G;
   size_t e256a, e256b, e256c, e128, e32a, e32b, e32c, e4;
   size_t dmod[3], b256a, b256b, b256c, b256d, b512, b2048, b8, bhid;
-  size_t wt;   // transposed weight block of the dX GEMM in flight (<= 1536 x 256 floats)
+  size_t wt;   // transposed weight block of the dX GEMM in flight (<= 1536 x 256 elements, fp32 or split bf16: 6 bytes each)
   size_t total;
 };
 static void bwd_layout(BwdLayout* L, int64_t N, int64_t E, int32_t B) {
@@ -31,7 +31,7 @@ static void bwd_layout(BwdLayout* L, int64_t N, int64_t E, int32_t B) {
   L->b256a = take((size_t)B * 256); L->b256b = take((size_t)B * 256); L->b256c = take((size_t)B * 256);
   L->b256d = take((size_t)B * 256); L->b512 = take((size_t)B * 512); L->b2048 = take((size_t)B * 2048);
   L->b8 = take((size_t)B * 8); L->bhid = take((size_t)B * 512);
-  L->wt = take(1536 * 256);
+  L->wt = take(1536 * 256 * 3 / 2);
   L->total = off;
 }
 
@@ -67,6 +67,20 @@ static void gemm_dx(const float* dY, int lddy, int M, int K, const float* W, int
   if (M <= 0) return;
   if (NT == 8 && use_cs() && g_wt_scratch != nullptr && ncols % 256 == 0 && K % G2_BK == 0 && lddy % 4 == 0 &&
       ncols / 256 <= 8 && (size_t)K * ncols <= 1536 * 256) {
+    if (split_gemm_enabled()) {   // split-operand mode: W^T goes straight into the split-bf16 block layout
+      uint16_t* ws = reinterpret_cast<uint16_t*>(g_wt_scratch);
+      hipLaunchKernelGGL(k_split_weight_t, dim3(ceil_div((K / 16) * ncols, 256)), dim3(256), 0, s, W, ldw, K, ncols, ws);
+      GemmCore g;
+      memset(&g, 0, sizeof g);
+      g.M = M; g.K = K; g.n_valid = 256; g.ldw = K;
+      SplitW sw;
+      memset(&sw, 0, sizeof sw);
+      for (int b = 0; b < ncols / 256; ++b) sw.blk[b] = ws + (size_t)b * (K / 16) * G4_CHUNK_ELEMS(4);
+      EpiBwdStore<8, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f};
+      hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBwdStore<8, MUL, ACCUM>, 4>), dim3(ceil_div(M, 128), ncols / 256),
+                         dim3(512), 0, s, g, sw, APtrPlain{dY, lddy}, e);
+      return;
+    }
     hipLaunchKernelGGL(k_transpose_block, dim3(ceil_div(ncols, 32), ceil_div(K, 32)), dim3(256), 0, s, W, K, ncols, ldw,
                        g_wt_scratch);
     GemmCore g = core_blocks(M, K, 256, g_wt_scratch, K, ncols / 256, 256);

@@ -84,6 +84,37 @@ static __global__ void k_split_weight(const float* __restrict__ W, int ldw, int 
   }
 }
 
+// Transposing variant for input-gradient GEMMs  dX = dY W  (W [K, ncols], row stride ldw): the B
+// operand is W^T, so element k of output column n is W[k, n].  One launch converts every 256-column
+// block; block b lands at out + b * (K / 16) * G4_CHUNK_ELEMS(4).  One thread per (block, chunk,
+// column), columns fastest, so the 16 strided loads of a thread are coalesced across the wave.
+static __global__ void k_split_weight_t(const float* __restrict__ W, int ldw, int K, int ncols,
+                                        uint16_t* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nk = K / 16;
+  if (idx >= nk * ncols) return;
+  const int n_all = idx % ncols, kc = idx / ncols;
+  const int b = n_all >> 8, n = n_all & 255;
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = W[(size_t)(kc * 16 + j) * ldw + n_all];
+  uint16_t* chunk = out + ((size_t)b * nk + kc) * G4_CHUNK_ELEMS(4);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u32x4 p[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k0 = (j < 2) ? 4 * h + 2 * j : 8 + 4 * h + 2 * (j - 2);
+      uint32_t a, bb, c;
+      split_pair(v[k0], v[k0 + 1], a, bb, c);
+      p[0][j] = a; p[1][j] = bb; p[2][j] = c;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<u32x4*>(chunk + ((size_t)(pl * 2 + h) * 256 + n) * 8) = p[pl];
+  }
+}
+
 // Stage buffers: W chunks (6 NTW KiB, L2-resident) are double-buffered; A chunks (8 KiB) have NSA
 // buffers.  With NSA = 3 a wave issues its W pieces of chunk kc + 1 and THEN its A piece of chunk
 // kc + 2, so "all but the newest DMA done" (s_waitcnt vmcnt(1)) is exactly "chunk kc + 1 landed";

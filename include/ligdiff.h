@@ -186,8 +186,8 @@ int ligdiff_loss_partial(const ligdiff_loss_args* args, float* sums8, void* stre
 int ligdiff_loss_finish(const ligdiff_loss_args* args, const float* sums8, float upstream,
                         float* losses32, float* d_atom, float* d_pos, float* d_prop, void* stream);
 
-/* Process-wide switch for how the forward pass (and the sampling loops built on it) multiplies its
- * fp32 matrices; returns the previous setting.  0 (default, or LIGDIFF_GEMM_SPLIT unset in the
+/* Process-wide switch for how the forward pass (and the sampling loops built on it), and the
+ * input-gradient products of ligdiff_backward, multiply their fp32 matrices; returns the previous setting.  0 (default, or LIGDIFF_GEMM_SPLIT unset in the
  * environment): v_mfma_f32_32x32x2_f32.  1: each fp32 operand is the exact sum of three bf16 numbers
  * and six of the nine partial products run on the bf16 matrix pipe with fp32 accumulation; the three
  * dropped products are below 2^-23 of the product, i.e. one fp32 rounding, so results agree with mode

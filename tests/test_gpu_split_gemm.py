@@ -118,8 +118,8 @@ def test_split_library_loop_graph_replay_host_loop_and_shards_agree_bitwise():
 
 
 def test_split_training_step_gradients_match_default_mode():
-    """Forward in split mode, backward on the fp32 pipe: losses and gradients stay within the
-    training tolerance of the default mode."""
+    """Forward and input-gradient GEMMs in split mode (weight gradients stay on the fp32 pipe): every
+    parameter gradient stays within the training tolerance of the default mode."""
     c = _random_batch([12, 29, 7, 18], 5)
     x, pos, ei, b = (torch.from_numpy(c[k]).cuda() for k in ("x", "pos", "edge_index", "batch"))
     t = torch.tensor([10.0, 500.0, 900.0, 3.0], device="cuda")
