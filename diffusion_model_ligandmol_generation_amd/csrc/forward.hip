@@ -322,12 +322,12 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     e.atom_mol = g->atom_mol; e.H = F(L.h0); e.ua_out = S(L.ua);
     PB("embed");
     if (use_cs()) {
-      hipLaunchKernelGGL(k_pad_embed, dim3(ceil_div(((long)N + 256) * 32, 256)), dim3(256), 0, s, x, w[W_ATOM_W],
-                         F(L.xpad), F(L.wpad), N);
-      // h = GELU(LN(x Wa^T + ba)) + R,  R = GELU(LN(pos Wp^T + bp)) + t_emb (+ prop_emb)
+      // h = GELU(LN(x Wa^T + ba)) + R,  R = GELU(LN(pos Wp^T + bp)) + t_emb (+ prop_emb); the same launch
+      // zero-extends x and Wa to 128 columns for the GEMM (64 extra workgroups for the weight rows)
       float* R = F(L.xn1[0]);   // free until the attention layers
-      hipLaunchKernelGGL(k_pos_embed, dim3(ceil_div(N, 4)), dim3(256), 0, s, pos, w[W_POS_W], w[W_POS_B], w[W_POS_G],
-                         w[W_POS_BE], F(L.temb), tstride, pemb, pstride, g->atom_mol, R, N);
+      hipLaunchKernelGGL(k_pos_embed, dim3(ceil_div(N, 4) + 64), dim3(256), 0, s, pos, w[W_POS_W], w[W_POS_B], w[W_POS_G],
+                         w[W_POS_BE], F(L.temb), tstride, pemb, pstride, g->atom_mol, R, N, x, w[W_ATOM_W], F(L.xpad),
+                         F(L.wpad));
       GemmCore gp = core_blocks(N, 128, 256, F(L.wpad), 128, 1, 256);
       EpiLN<ACT_NONE, ACT_GELU, true> el;
       memset(&el, 0, sizeof el);

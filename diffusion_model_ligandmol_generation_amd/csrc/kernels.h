@@ -94,33 +94,38 @@ __global__ __launch_bounds__(256) void k_edge_geom(
   }
 }
 
-// Zero-extends the 119-wide atom features and the atom-embedding weight rows to 128 floats
-// (512-B rows), the form the LDS-DMA GEMM needs (16-B aligned rows, K a multiple of 16).
-// Rows [0,N) come from x, rows [N, N+256) from W; one thread writes 16 B.
-__global__ __launch_bounds__(256) void k_pad_embed(const float* __restrict__ x, const float* __restrict__ W,
-                                                   float* __restrict__ xpad, float* __restrict__ wpad, int N) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long row = i >> 5;
-  const int q = (int)(i & 31) * 4;
-  if (row >= (long)N + 256) return;
-  const float* src = row < N ? x + row * LD_A : W + (row - N) * LD_A;
-  float* dst = row < N ? xpad + row * 128 : wpad + (row - N) * 128;
-  f32x4 v;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = (q + e) < LD_A ? src[q + e] : 0.f;
-  *reinterpret_cast<f32x4*>(dst + q) = v;
-}
-
 // Position / time part of the input embedding, model1.py:710-718 (one wave per atom):
 //   R = GELU(LN(pos Wp^T + bp)) + t_emb[mol] (+ prop_emb[mol])
 // The atom-feature GEMM adds its own LayerNorm + GELU branch on top of R in its epilogue.
+// With xpad != NULL the same launch also zero-extends the 119-wide atom features and the atom-embedding
+// weight rows to 128 floats (512-B rows: the form the LDS-DMA GEMM needs, 16-B aligned rows and K a
+// multiple of 16): the wave of atom `row` writes that atom's row of xpad, and 64 extra workgroups
+// (blockIdx.x >= ceil(N / 4)) write the 256 rows of wpad.
 __global__ __launch_bounds__(256) void k_pos_embed(const float* __restrict__ pos, const float* __restrict__ Wp,
                                                    const float* __restrict__ bp, const float* __restrict__ gp,
                                                    const float* __restrict__ bep, const float* __restrict__ temb,
                                                    int temb_stride, const float* __restrict__ pemb, int pemb_stride,
-                                                   const int32_t* __restrict__ atom_mol, float* __restrict__ R, int N) {
+                                                   const int32_t* __restrict__ atom_mol, float* __restrict__ R, int N,
+                                                   const float* __restrict__ x = nullptr, const float* __restrict__ Wa = nullptr,
+                                                   float* __restrict__ xpad = nullptr, float* __restrict__ wpad = nullptr) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (xpad != nullptr && lane < 32) {
+    const int nb_atoms = (N + 3) >> 2;
+    const float* src = nullptr;
+    float* dst = nullptr;
+    if (row < N) { src = x + (size_t)row * LD_A; dst = xpad + (size_t)row * 128; }
+    else if ((int)blockIdx.x >= nb_atoms && row - nb_atoms * 4 < 256) {
+      src = Wa + (size_t)(row - nb_atoms * 4) * LD_A; dst = wpad + (size_t)(row - nb_atoms * 4) * 128;
+    }
+    if (src != nullptr) {
+      const int q = lane * 4;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (q + e) < LD_A ? src[q + e] : 0.f;
+      *reinterpret_cast<f32x4*>(dst + q) = v;
+    }
+  }
   if (row >= N) return;
   const float p0 = pos[(size_t)row * 3 + 0], p1 = pos[(size_t)row * 3 + 1], p2 = pos[(size_t)row * 3 + 2];
   const int mol = atom_mol[row];
