@@ -298,6 +298,28 @@ int main() {
         ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiNull>), dim3(232, 4), dim3(512), 0, 0, g, ap, en); }, 50);
         report("fp32         M29696 K256 N1024 no epi", ms, 2.0 * M * 256 * 1024);
       }
+      {  // 128-column blocks (two accumulators per wave): twice the workgroups
+        uint16_t* Ws2;
+        CK(hipMalloc(&Ws2, (size_t)1024 * 256 * 6));
+        SplitW sw2; memset(&sw2, 0, sizeof sw2);
+        for (int b = 0; b < 8; ++b) {
+          uint16_t* dst = Ws2 + (size_t)b * 16 * G4_CHUNK_ELEMS(2);
+          hipLaunchKernelGGL(k_split_weight, dim3((128 * 16 + 255) / 256), dim3(256), 0, 0, W + (size_t)b * 128 * 256, 256, 128, 256, 128, dst);
+          sw2.blk[b] = dst;
+        }
+        GemmCore g4; memset(&g4, 0, sizeof g4);
+        g4.M = M; g4.K = 256; g4.n_valid = 128; g4.ldw = 256;
+        for (int i = 0; i < 8; ++i) g4.W[i] = W + (size_t)i * 128 * 256;
+        EpiBiasAct<4, ACT_GELU, false> e4; memset(&e4, 0, sizeof e4);
+        e4.M = M; e4.n_valid = 128; e4.col_block = 128; e4.C = C; e4.ldc = 1024; e4.alpha = 1.f;
+        for (int i = 0; i < 8; ++i) e4.bias[i] = bias + i * 128;
+        for (int rep = 0; rep < 3; ++rep) {
+          ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<4, ACT_GELU, false>, 2>), dim3(232, 8), dim3(512), 0, 0, g4, sw2, ap, e4); }, 50);
+          report("split 128-col ffn_up M29696 K256 N1024 GELU", ms, 2.0 * M * 256 * 1024);
+          ms = time_it([&] { hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8, ACT_GELU, false>, 4>), dim3(232, 4), dim3(512), 0, 0, g, sw, ap, e); }, 50);
+          report("split 256-col ffn_up M29696 K256 N1024 GELU", ms, 2.0 * M * 256 * 1024);
+        }
+      }
       // accuracy: plain store epilogue, both kernels against a double-precision host product
       EpiBiasAct<8, ACT_NONE, false> e0; memcpy(&e0, &e, sizeof e);
       for (int i = 0; i < 4; ++i) e0.bias[i] = nullptr;
