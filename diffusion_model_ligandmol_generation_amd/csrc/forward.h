@@ -29,6 +29,8 @@ struct FwdLayout {
 };
 // Split-operand GEMM mode of the forward pass (process-wide; see ligdiff_set_split_gemm).
 bool split_gemm_enabled();
+// True unless an environment A/B switch routed the GEMMs to the register-staged kernels.
+bool fwd_column_split_gemms();
 void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags);
 
 // Measurement hook: the launch whose label equals `label` is bracketed by e0 / e1.
@@ -38,6 +40,11 @@ struct FwdProbe { const char* label; hipEvent_t e0, e1; int hits; };
 // (temb [1,256] and the three adaLN rows mod[l] [1,1536]) were filled by the caller, so the forward
 // skips its time path.  Only meaningful together with LIGDIFF_FWD_T_BROADCAST.
 #define FWD_INTERNAL_TIME_GIVEN (1 << 20)
+// Library-internal flag: the batch is a conditional half followed by an unconditional copy of the same
+// molecules (classifier-free guidance in one pass): `properties` has n_mols / 2 rows and only the
+// first n_mols / 2 molecules receive the property embedding.  Needs LIGDIFF_FWD_PROPERTIES, no null
+// conditioning, no saved activations.
+#define FWD_INTERNAL_HALF_COND (1 << 21)
 
 // Time embedding + adaLN parameters for n_rows timesteps t[0..n_rows) with the kernels (and the
 // per-row summation order) of the shared-timestep path: temb [n,256], mod_l [n,1536];

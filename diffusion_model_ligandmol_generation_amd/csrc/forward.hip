@@ -127,6 +127,7 @@ bool split_gemm_enabled() {
   }
   return m != 0;
 }
+bool fwd_column_split_gemms() { return use_cs(); }
 extern "C" int ligdiff_set_split_gemm(int enabled) {
   const int prev = split_gemm_enabled() ? 1 : 0;
   g_split_mode.store(enabled ? 1 : 0, std::memory_order_relaxed);
@@ -292,6 +293,12 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   // --- PILOT conditioning (model1.py:714-718, :335-359)
   const float* pemb = nullptr;
   int pstride = 0;
+  int pemb_mols = B;   // molecules that receive the property embedding
+  if (flags & FWD_INTERNAL_HALF_COND) {
+    if (!(flags & LIGDIFF_FWD_PROPERTIES) || (flags & LIGDIFF_FWD_NULL_COND) || L.save || (B & 1) || !use_cs())
+      return LIGDIFF_ERR_ARG;
+    pemb_mols = B / 2;
+  }
   if (flags & LIGDIFF_FWD_PROPERTIES) {
     if (flags & LIGDIFF_FWD_NULL_COND) {
       pemb = w[W_NULL_EMB]; pstride = 0;
@@ -302,10 +309,10 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         pw.w0[i] = w[W_PENC(i, 0)]; pw.b0[i] = w[W_PENC(i, 1)];
         pw.W2[i] = w[W_PENC(i, 2)]; pw.b2[i] = w[W_PENC(i, 3)];
       }
-      hipLaunchKernelGGL(k_pilot_encode, dim3(B), dim3(256), 0, s, properties, pw, F(L.pstack), S(L.pen_pre));
-      gemm_bias_act<ACT_GELU, false>(F(L.pstack), 2048, B, 2048, w[W_PAR0_W], 2048, w[W_PAR0_B], 1, F(L.pg), 256, nullptr, s,
-                                     S(L.pg_pre));
-      hipLaunchKernelGGL(k_pilot_combine, dim3(B), dim3(256), 0, s, F(L.pg), w[W_PAR2_W], w[W_PAR2_B], F(L.pstack), F(L.pemb),
+      hipLaunchKernelGGL(k_pilot_encode, dim3(pemb_mols), dim3(256), 0, s, properties, pw, F(L.pstack), S(L.pen_pre));
+      gemm_bias_act<ACT_GELU, false>(F(L.pstack), 2048, pemb_mols, 2048, w[W_PAR0_W], 2048, w[W_PAR0_B], 1, F(L.pg), 256,
+                                     nullptr, s, S(L.pg_pre));
+      hipLaunchKernelGGL(k_pilot_combine, dim3(pemb_mols), dim3(256), 0, s, F(L.pg), w[W_PAR2_W], w[W_PAR2_B], F(L.pstack), F(L.pemb),
                          S(L.pz), S(L.pw));
       pemb = F(L.pemb); pstride = 256;
     }
@@ -326,8 +333,8 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       // zero-extends x and Wa to 128 columns for the GEMM (64 extra workgroups for the weight rows)
       float* R = F(L.xn1[0]);   // free until the attention layers
       hipLaunchKernelGGL(k_pos_embed, dim3(ceil_div(N, 4) + 64), dim3(256), 0, s, pos, w[W_POS_W], w[W_POS_B], w[W_POS_G],
-                         w[W_POS_BE], F(L.temb), tstride, pemb, pstride, g->atom_mol, R, N, x, w[W_ATOM_W], F(L.xpad),
-                         F(L.wpad));
+                         w[W_POS_BE], F(L.temb), tstride, pemb, pstride, g->atom_mol, R, N, pemb_mols, x, w[W_ATOM_W],
+                         F(L.xpad), F(L.wpad));
       GemmCore gp = core_blocks(N, 128, 256, F(L.wpad), 128, 1, 256);
       EpiLN<ACT_NONE, ACT_GELU, true> el;
       memset(&el, 0, sizeof el);

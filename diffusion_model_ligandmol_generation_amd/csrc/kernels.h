@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void k_pos_embed(const float* __restrict__ pos
                                                    const float* __restrict__ bep, const float* __restrict__ temb,
                                                    int temb_stride, const float* __restrict__ pemb, int pemb_stride,
                                                    const int32_t* __restrict__ atom_mol, float* __restrict__ R, int N,
+                                                   int pemb_mols,   // molecules [0, pemb_mols) receive pemb
                                                    const float* __restrict__ x = nullptr, const float* __restrict__ Wa = nullptr,
                                                    float* __restrict__ xpad = nullptr, float* __restrict__ wpad = nullptr) {
   const int lane = threadIdx.x & 63;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void k_pos_embed(const float* __restrict__ pos
   f32x4 o;
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = gelu_exact(d[i] * rstd * g[i] + b[i]) + t[i];
-  if (pemb != nullptr) o += *reinterpret_cast<const f32x4*>(pemb + (size_t)mol * pemb_stride + lane * 4);
+  if (pemb != nullptr && mol < pemb_mols) o += *reinterpret_cast<const f32x4*>(pemb + (size_t)mol * pemb_stride + lane * 4);
   *reinterpret_cast<f32x4*>(R + (size_t)row * 256 + lane * 4) = o;
 }
 

@@ -1,5 +1,6 @@
 // Reverse-diffusion updates (generation.py:457-484 DDPM, :359-381 DDIM) and the
 // graph-captured sampling loop (generation.py:422).
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -225,18 +226,42 @@ extern "C" int ligdiff_ddim_step(const ligdiff_step_args* a, int32_t t_cur, int3
 // path); each step then copies its row into the forward's shared-timestep buffers with one small
 // launch that also advances the step counter.
 #define TIME_ROW_FLOATS (256 + 3 * 1536)
+// Guided sampling (classifier-free guidance) evaluates the network on the conditional batch and on an
+// unconditional copy of it.  Both run as ONE forward over a doubled batch (molecules [0, B) with the
+// property embedding, [B, 2B) without): twice the rows per launch fills the GPU where B molecules
+// alone leave most GEMMs at one workgroup per CU.  Molecules never interact, so the result equals two
+// separate passes bit for bit.  LIGDIFF_CFG_TWO_PASS=1 keeps the two-pass form (A/B switch used by the tests).
+static bool cfg_one_pass() {   // read per call: the tests flip it within one process
+  return getenv("LIGDIFF_CFG_TWO_PASS") == nullptr && fwd_column_split_gemms();
+}
 struct SampleLayout {
-  size_t fwd, eps_x, eps_pos, eps_xu, eps_pu, t_index, tvals, tf, t1, stemb, tab_temb, tab_mod[3], total;
+  size_t fwd, eps_x, eps_pos, eps_xu, eps_pu, t_index, tvals, tf, t1, stemb, tab_temb, tab_mod[3];
+  // doubled batch of the one-pass guided form: state copies and the int32 arrays of its ligdiff_graph
+  size_t x2, pos2, g_mol_ptr, g_atom_mol, g_dst_ptr, g_src_ptr, g_src, g_dst, g_src_slot;
+  size_t total;
 };
 static void sample_layout(SampleLayout* L, int64_t N, int64_t E, int32_t B, int guided, int32_t n_steps) {
+  memset(L, 0, sizeof *L);
+  const bool one_pass = guided && cfg_one_pass();
+  const int64_t m = one_pass ? 2 : 1;   // batch multiplier of the forward
   FwdLayout F;
-  fwd_layout(&F, N, E, B, LIGDIFF_FWD_T_BROADCAST);
+  fwd_layout(&F, m * N, m * E, (int32_t)(m * B), LIGDIFF_FWD_T_BROADCAST);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
   L->fwd = take(F.total);
-  L->eps_x = take((size_t)N * LD_A * 4); L->eps_pos = take((size_t)N * 3 * 4);
-  L->eps_xu = guided ? take((size_t)N * LD_A * 4) : 0;
-  L->eps_pu = guided ? take((size_t)N * 3 * 4) : 0;
+  if (one_pass) {   // conditional and unconditional predictions are the two halves of one output
+    L->eps_x = take((size_t)2 * N * LD_A * 4); L->eps_pos = take((size_t)2 * N * 3 * 4);
+    L->eps_xu = L->eps_x + (size_t)N * LD_A * 4;
+    L->eps_pu = L->eps_pos + (size_t)N * 3 * 4;
+    L->x2 = take((size_t)2 * N * LD_A * 4); L->pos2 = take((size_t)2 * N * 3 * 4);
+    L->g_mol_ptr = take((size_t)(2 * B + 1) * 4); L->g_atom_mol = take((size_t)2 * N * 4);
+    L->g_dst_ptr = take((size_t)(2 * N + 1) * 4); L->g_src_ptr = take((size_t)(2 * N + 1) * 4);
+    L->g_src = take((size_t)2 * E * 4 + 4); L->g_dst = take((size_t)2 * E * 4 + 4); L->g_src_slot = take((size_t)2 * E * 4 + 4);
+  } else {
+    L->eps_x = take((size_t)N * LD_A * 4); L->eps_pos = take((size_t)N * 3 * 4);
+    L->eps_xu = guided ? take((size_t)N * LD_A * 4) : 0;
+    L->eps_pu = guided ? take((size_t)N * 3 * 4) : 0;
+  }
   L->t_index = take(256);
   const size_t T = (size_t)(n_steps > 0 ? n_steps : 1);
   L->tvals = take(T * 4); L->tf = take(T * 256 * 4); L->t1 = take(T * 512 * 4); L->stemb = take(T * 256 * 4);
@@ -332,6 +357,34 @@ __global__ void k_prediction_gate_guided(ligdiff_step_args a, const int32_t* __r
   if (!(fabsf(v) <= 100.0f)) reject[atom_mol[atom]] = 1;  // also true for NaN
 }
 
+// Arrays of the doubled batch: the second copy of every molecule, atom and edge carries index + B / N / E.
+struct DoubleGraphArgs {
+  const int32_t *mol_ptr, *atom_mol, *dst_ptr, *src_ptr, *src, *dst, *src_slot;
+  int32_t *mol_ptr2, *atom_mol2, *dst_ptr2, *src_ptr2, *src2, *dst2, *src_slot2;
+  int N, E, B;
+};
+__global__ void k_double_graph(DoubleGraphArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= a.B) { a.mol_ptr2[i] = a.mol_ptr[i]; a.mol_ptr2[a.B + i] = a.mol_ptr[i] + a.N; }
+  if (i <= a.N) {
+    a.dst_ptr2[i] = a.dst_ptr[i]; a.dst_ptr2[a.N + i] = a.dst_ptr[i] + a.E;
+    a.src_ptr2[i] = a.src_ptr[i]; a.src_ptr2[a.N + i] = a.src_ptr[i] + a.E;
+  }
+  if (i < a.N) { a.atom_mol2[i] = a.atom_mol[i]; a.atom_mol2[a.N + i] = a.atom_mol[i] + a.B; }
+  if (i < a.E) {
+    a.src2[i] = a.src[i]; a.src2[a.E + i] = a.src[i] + a.N;
+    a.dst2[i] = a.dst[i]; a.dst2[a.E + i] = a.dst[i] + a.N;
+    a.src_slot2[i] = a.src_slot[i]; a.src_slot2[a.E + i] = a.src_slot[i] + a.E;
+  }
+}
+// x2 = [x; x], pos2 = [pos; pos]  (nx, np: element counts of x and pos)
+__global__ void k_dup_state(const float* __restrict__ x, const float* __restrict__ pos, float* __restrict__ x2,
+                            float* __restrict__ pos2, int64_t nx, int64_t np) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nx) { const float v = x[i]; x2[i] = v; x2[nx + i] = v; }
+  else if (i < nx + np) { const float v = pos[i - nx]; pos2[i - nx] = v; pos2[np + i - nx] = v; }
+}
+
 // Shared loop of the DDPM sampler (ddim_ts == NULL: step index counts down from n_steps - 1 and is the
 // timestep) and of the DDIM sampler (ddim_ts [n_steps] device int32: loop position counts up, the
 // timestep is ddim_ts[position]; `reject` [n_mols] collects the per-step prediction gate).
@@ -363,8 +416,24 @@ static int sample_loop(const float* const* weights, const ligdiff_graph* graph, 
   int rc = run_time_rows(weights, WF(L.tvals), n_steps, WF(L.tf), WF(L.t1), WF(L.tab_temb), WF(L.stemb),
                          WF(L.tab_mod[0]), WF(L.tab_mod[1]), WF(L.tab_mod[2]), s);
   if (rc) return rc;
+  const bool one_pass = guided && cfg_one_pass();
+  const int64_t N1 = graph->n_atoms, E1 = graph->n_edges;
+  const int32_t B1 = graph->n_mols;
+  if (one_pass && (2 * N1 >= (1LL << 30) || 2 * E1 >= (1LL << 30))) return LIGDIFF_ERR_ARG;
+  ligdiff_graph graph2 = *graph;
+  if (one_pass) {
+    auto WI = [&](size_t off) { return (int32_t*)(ws + off); };
+    DoubleGraphArgs d{graph->mol_ptr, graph->atom_mol, graph->dst_ptr, graph->src_ptr, graph->src, graph->dst,
+                      graph->src_slot, WI(L.g_mol_ptr), WI(L.g_atom_mol), WI(L.g_dst_ptr), WI(L.g_src_ptr), WI(L.g_src),
+                      WI(L.g_dst), WI(L.g_src_slot), (int)N1, (int)E1, (int)B1};
+    const int64_t span = (N1 > E1 ? N1 : E1) + 1;
+    hipLaunchKernelGGL(k_double_graph, dim3(ceil_div(span > B1 + 1 ? span : B1 + 1, 256)), dim3(256), 0, s, d);
+    graph2.n_atoms = 2 * N1; graph2.n_edges = 2 * E1; graph2.n_mols = 2 * B1;
+    graph2.mol_ptr = d.mol_ptr2; graph2.atom_mol = d.atom_mol2; graph2.dst_ptr = d.dst_ptr2; graph2.src_ptr = d.src_ptr2;
+    graph2.src = d.src2; graph2.dst = d.dst2; graph2.src_slot = d.src_slot2; graph2.perm = nullptr;
+  }
   FwdLayout FL;
-  fwd_layout(&FL, graph->n_atoms, graph->n_edges, graph->n_mols, LIGDIFF_FWD_T_BROADCAST);
+  fwd_layout(&FL, graph2.n_atoms, graph2.n_edges, graph2.n_mols, LIGDIFF_FWD_T_BROADCAST);
   TimeGatherArgs tg;
   tg.tab_temb = WF(L.tab_temb); tg.temb = WF(L.fwd + FL.temb);
   for (int l = 0; l < 3; ++l) { tg.tab_mod[l] = WF(L.tab_mod[l]); tg.mod[l] = WF(L.fwd + FL.mod[l]); }
@@ -381,6 +450,13 @@ static int sample_loop(const float* const* weights, const ligdiff_graph* graph, 
   const int base = LIGDIFF_FWD_T_BROADCAST | LIGDIFF_FWD_SKIP_PROP_HEAD | FWD_INTERNAL_TIME_GIVEN;
   SplitCache split;   // split-operand mode: weight blocks converted once for the whole loop
   auto forwards = [&]() -> int {
+    if (one_pass) {
+      const int64_t nx = N1 * LD_A, np = N1 * 3;
+      hipLaunchKernelGGL(k_dup_state, dim3(ceil_div(nx + np, 256)), dim3(256), 0, s, x, pos, WF(L.x2), WF(L.pos2), nx, np);
+      return run_forward(weights, &graph2, WF(L.x2), WF(L.pos2), nullptr, counter + 1, properties,
+                         base | LIGDIFF_FWD_PROPERTIES | FWD_INTERNAL_HALF_COND, WF(L.eps_x), WF(L.eps_pos), nullptr,
+                         ws + L.fwd, s, nullptr, &split);
+    }
     int r = run_forward(weights, graph, x, pos, nullptr, counter + 1, properties,
                         base | (properties ? LIGDIFF_FWD_PROPERTIES : 0), WF(L.eps_x), WF(L.eps_pos), nullptr,
                         ws + L.fwd, s, nullptr, &split);
