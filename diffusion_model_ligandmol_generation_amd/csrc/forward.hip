@@ -469,7 +469,19 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       const int tk = (max_n + 31) / 32;
       const size_t lds = (size_t)4 * 2 * (tk * 32) * 33 * 4;
       const int blocks = ceil_div((long)B * 8 * tk, 4);
-      if (tk == 1)
+      static const bool att_lds = getenv("LIGDIFF_ATT_LDS") != nullptr;   // A/B switch: LDS-staged form
+      const float* qkv_l = F(L.qkv[l]);
+      float* att_l = F(L.att[l]);
+      float* lse_l = S(L.lse[l]);
+      if (!att_lds && tk == 1)
+        hipLaunchKernelGGL(k_attention_reg<1>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B);
+      else if (!att_lds && tk == 2)
+        hipLaunchKernelGGL(k_attention_reg<2>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B);
+      else if (!att_lds && tk == 3)
+        hipLaunchKernelGGL(k_attention_reg<3>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B);
+      else if (!att_lds)
+        hipLaunchKernelGGL(k_attention_reg<4>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B);
+      else if (tk == 1)
         hipLaunchKernelGGL(k_attention_mfma<1>, dim3(blocks), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]), S(L.lse[l]), B);
       else if (tk == 2)
         hipLaunchKernelGGL(k_attention_mfma<2>, dim3(blocks), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]), S(L.lse[l]), B);

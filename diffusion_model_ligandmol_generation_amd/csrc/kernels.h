@@ -410,6 +410,102 @@ __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict_
   }
 }
 
+// Register-only form of k_attention_mfma (same products, same ownership: one wave per molecule, head
+// and 32-query tile), without LDS and without a barrier.  The k index of an MFMA step is free as long
+// as both operands agree, so step s of lane half h takes head dimension d = 16 h + s: a lane's 16
+// values of its K row (and of its Q row) are then CONTIGUOUS - four 16-B loads straight from qkv into
+// the operand registers.  For O^T = V^T P^T lane (d, h) needs V[j(r, h), d] for its 16 keys: 16 dword
+// loads, each a coalesced 128-B row segment per lane half.  Rows beyond n are clamped to the last atom
+// (their scores are masked to -inf, their probabilities are exactly 0).
+template <int TK>
+__global__ __launch_bounds__(256) void k_attention_reg(const float* __restrict__ qkv,
+                                                       const int32_t* __restrict__ mol_ptr,
+                                                       float* __restrict__ out, float* __restrict__ lse_out,
+                                                       int n_mols) {
+  constexpr int ITEMS = 8 * TK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = blockIdx.x * 4 + wave;
+  const int mol = item / ITEMS, rem = item % ITEMS;
+  const int head = rem / TK, qt = rem % TK;
+  if (mol >= n_mols) return;
+  const int a0 = mol_ptr[mol], n = mol_ptr[mol + 1] - a0;
+  if (qt * 32 >= n) return;
+  const int fi = lane & 31, h = lane >> 5;
+  const int qi = qt * 32 + fi;
+  const float scale = 0.17677669529663687f;       // 1/sqrt(32)
+  const float* base = qkv + (size_t)a0 * 768 + head * 32;
+  float q[16];
+  {
+    const float* qp = base + (size_t)(qi < n ? qi : n - 1) * 768 + 16 * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qp + c * 4);
+      q[c * 4 + 0] = v[0] * scale; q[c * 4 + 1] = v[1] * scale; q[c * 4 + 2] = v[2] * scale; q[c * 4 + 3] = v[3] * scale;
+    }
+  }
+  f32x16 sc[TK];
+#pragma unroll
+  for (int t = 0; t < TK; ++t) {
+    const int kr = t * 32 + fi;
+    const float* kp = base + (size_t)(kr < n ? kr : n - 1) * 768 + 256 + 16 * h;
+    f32x4 kf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const f32x4*>(kp + c * 4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)   // A = K[t*32 + fi, 16h + 4c + e], B = scale Q[qi, same d]
+        sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c][e], q[c * 4 + e], sc[t], 0, 0, 0);
+  }
+  float vf[TK][16];   // V[j(r, h), d = fi], fetched while the softmax runs
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int vr = t * 32 + G_ROW_ATT(r, h);
+      vf[t][r] = base[(size_t)(vr < n ? vr : n - 1) * 768 + 512 + fi];
+    }
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = t * 32 + G_ROW_ATT(r, h);
+      sc[t][r] = j < n ? sc[t][r] : -INFINITY;
+      m = fmaxf(m, sc[t][r]);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(sc[t][r] - m);
+      sc[t][r] = p;
+      l += p;
+    }
+  l += __shfl_xor(l, 32);
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t][r], sc[t][r], o, 0, 0, 0);
+  if (qi < n) {
+    const float inv = 1.0f / l;
+    float* op = out + (size_t)(a0 + qi) * 256 + head * 32;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {   // registers 4g..4g+3 are d = 8g + 4h + (0..3)
+      f32x4 v = {o[gq * 4 + 0] * inv, o[gq * 4 + 1] * inv, o[gq * 4 + 2] * inv, o[gq * 4 + 3] * inv};
+      *reinterpret_cast<f32x4*>(op + gq * 8 + h * 4) = v;
+    }
+    if (lse_out != nullptr && h == 0) lse_out[(size_t)(a0 + qi) * 8 + head] = m + logf(l);
+  }
+}
+
 // out[row, o] = y[row, off:off+256] . W[o, :] + b[o] (+ add[row, o]); final layers of
 // the coordinate (3) and property (15) heads, model1.py:647 / :654 / :742.
 template <int NOUT>
