@@ -100,9 +100,35 @@ __global__ __launch_bounds__(256) void k_reverse_step_ddpm(ligdiff_step_args a) 
   const StepCoef k = ddpm_coef(a.betas, a.alphas, a.alphas_cumprod, t, a.temperature);
   f32x4 z = {0.f, 0.f, 0.f, 0.f};
   if (t > 0 && k.add_noise && nz == nullptr) z = philox_normal4(a.seed, (uint32_t)t, is_pos ? 1u : 0u, quad);
+  const int64_t j0 = (int64_t)(quad * 4) - g0;
+  // whole quad inside the array and 16-B aligned (always so for a single shard at offset 0): vector form
+  if (j0 >= 0 && j0 + 3 < n && (j0 & 3) == 0 &&
+      ((reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(ec) | reinterpret_cast<uintptr_t>(eu) |
+        reinterpret_cast<uintptr_t>(nz)) & 15) == 0) {
+    f32x4 eps = *reinterpret_cast<const f32x4*>(ec + j0);
+    if (eu != nullptr) {  // generation.py:442-443
+      const f32x4 u = *reinterpret_cast<const f32x4*>(eu + j0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) eps[e] = u[e] + a.guidance_scale * (eps[e] - u[e]);
+    }
+    const f32x4 v = *reinterpret_cast<const f32x4*>(state + j0);
+    if (nz != nullptr && t > 0 && k.add_noise) z = *reinterpret_cast<const f32x4*>(nz + j0);
+    f32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (t > 0) {
+        out[e] = k.a * (v[e] - k.b * eps[e]);
+        if (k.add_noise) out[e] += (z[e] * k.c) * a.temperature;
+      } else {
+        out[e] = (v[e] - k.b * eps[e]) / k.c;
+      }
+    }
+    *reinterpret_cast<f32x4*>(state + j0) = out;
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int64_t j = (int64_t)(quad * 4 + e) - g0;   // local element
+    const int64_t j = j0 + e;   // local element
     if (j < 0 || j >= n) continue;
     float eps = ec[j];
     if (eu != nullptr) {  // generation.py:442-443
