@@ -172,9 +172,15 @@ def main():
     eng.set_split_gemm(split_mode)
     dt, accepted, x, pos = timed_run(args.warmup, args.steps)
     finite = bool(torch.isfinite(x).all() and torch.isfinite(pos).all())
-    eng.set_split_gemm(not split_mode)
-    dt_alt, _, x_alt, pos_alt = timed_run(1, args.steps)
-    eng.set_split_gemm(split_mode)
+    # (every rank runs it, so the barriers inside stay matched; a failure here must not lose the headline)
+    alt_error = None
+    try:
+        eng.set_split_gemm(not split_mode)
+        dt_alt, _, x_alt, pos_alt = timed_run(1, args.steps)
+    except Exception as e:   # noqa: BLE001
+        alt_error = repr(e)
+    finally:
+        eng.set_split_gemm(split_mode)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -202,7 +208,15 @@ def main():
                     "fp32_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
                     "note": "achieved counts the six bf16 MFMA products issued per fp32 product"}
         roofline = ffn_up_roofline(split_mode)
-        roofline_alt = ffn_up_roofline(not split_mode)
+        if alt_error is None:
+            alt = {"gemm_mode": mode_name(not split_mode),
+                   "value": world * MOLS_PER_GPU * args.steps / dt_alt, "unit": "molecules/s",
+                   "ms_per_step": dt_alt / args.steps * 1e3,
+                   "max_abs_diff_vs_headline": {"x": float((x_alt - x).abs().max()),
+                                                "pos": float((pos_alt - pos).abs().max())},
+                   "roofline": ffn_up_roofline(not split_mode)}
+        else:
+            alt = {"gemm_mode": mode_name(not split_mode), "error": alt_error}
         # ---- the aggregation kernel against the HBM roofline (north-star target kernel)
         E = graph.n_edges
         ms_agg = eng.time_launch("e3_1.aggregate", graph, x, pos, t_index, reps=10)
@@ -226,12 +240,7 @@ def main():
             "accepted_rank0": accepted, "finite": finite,
             "roofline": roofline, "roofline_aggregation": roofline_agg,
             # the same K passes in the library's other GEMM mode (not the headline; see config.gemm_mode)
-            "alt_gemm_mode": {"gemm_mode": mode_name(not split_mode),
-                              "value": world * MOLS_PER_GPU * args.steps / dt_alt, "unit": "molecules/s",
-                              "ms_per_step": dt_alt / args.steps * 1e3,
-                              "max_abs_diff_vs_headline": {"x": float((x_alt - x).abs().max()),
-                                                           "pos": float((pos_alt - pos).abs().max())},
-                              "roofline": roofline_alt},
+            "alt_gemm_mode": alt,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
