@@ -312,8 +312,9 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
         colsum(e256b, 256, E, 256, nullptr, gr[W_E3(l, E3_EN2_B)], s);
       gemm_dx<8, MUL_SILU_GRAD, false>(e256b, 256, E, 256, w[W_E3(l, E3_EN2_W)], 256, 256, dpre, 256, A(F.pre_e[l]),
                                        256, s);
-      // pre = Pa[src] + Pb[dst] + Wc rbf + b1
-      colsum(dpre, 256, E, 256, nullptr, gr[W_E3(l, E3_EN0_B)], s);
+      // pre = Pa[src] + Pb[dst] + Wc rbf + b1.  The bias gradient sum_e dpre[e] equals the column sum of
+      // the per-destination gather dP[:, 256:512] (every edge has exactly one destination atom), which
+      // the weight-gradient GEMM on that block produces in the same pass (N rows instead of E).
       gemm_dw<4>(dpre, 256, 256, A(F.rbf[l]), 32, 32, E, dW1 + 512, 544, s);
       float* drbf = T(L.e32a);
       gemm_dx<4, MUL_NONE, false>(dpre, 256, E, 256, W1 + 512, 544, 32, drbf, 32, nullptr, 0, s);
@@ -321,14 +322,14 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
       float* r1 = T(L.e32c);
       hipLaunchKernelGGL(k_radial_bwd, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, A(F.r1pre[l]), A(F.dist[l]),
                          A(F.rel[l]), w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB2_W)], drel, dr1pre, r1, E);
-      if (!gemm_dw<4>(drbf, 32, 32, r1, 32, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s, gr[W_E3(l, E3_RB2_B)]))
-        colsum(drbf, 32, E, 32, nullptr, gr[W_E3(l, E3_RB2_B)], s);
-      colsum(dr1pre, 32, E, 32, A(F.dist[l]), gr[W_E3(l, E3_RB0_W)], s);
-      colsum(dr1pre, 32, E, 32, nullptr, gr[W_E3(l, E3_RB0_B)], s);
+      gemm_dw<4>(drbf, 32, 32, r1, 32, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s);   // 32-wide: register-staged kernel, no bias sum
+      hipLaunchKernelGGL(k_radial_colsums, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, dr1pre, A(F.dist[l]),
+                         gr[W_E3(l, E3_RB2_B)], gr[W_E3(l, E3_RB0_W)], gr[W_E3(l, E3_RB0_B)], E);
       float* dP = T(L.n512);
       hipLaunchKernelGGL(k_dp_gather, dim3(nb4N), dim3(256), 0, s, dpre, g->dst_ptr, g->src_ptr, g->src_slot, dP, N);
       gemm_dw<8>(dP, 512, 256, h_in, 256, 256, N, dW1, 544, s);
-      gemm_dw<8>(dP + 256, 512, 256, h_in, 256, 256, N, dW1 + 256, 544, s);
+      if (!gemm_dw<8>(dP + 256, 512, 256, h_in, 256, 256, N, dW1 + 256, 544, s, gr[W_E3(l, E3_EN0_B)]))
+        colsum(dpre, 256, E, 256, nullptr, gr[W_E3(l, E3_EN0_B)], s);
       gemm_dx<8, MUL_NONE, true>(dP, 512, N, 256, W1, 544, 256, dxa, 256, nullptr, 0, s);
       gemm_dx<8, MUL_NONE, true>(dP + 256, 512, N, 256, W1 + 256, 544, 256, dxa, 256, nullptr, 0, s);
       if (l > 0)  // layer 0 reads the data coordinates: no parameter lies upstream of them

@@ -52,6 +52,33 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ Y, int
   atomicAdd(out + c, s);
 }
 
+// The three 32-wide column sums of the radial MLP backward in one pass over the edges (model1.py:56-60):
+//   out_b2[c] += sum_e drbf[e, c];  out_w0[c] += sum_e dr1pre[e, c] dist[e];  out_b0[c] += sum_e dr1pre[e, c]
+// 256 threads = 8 row groups x 32 columns over 256 edges per workgroup.
+__global__ __launch_bounds__(256) void k_radial_colsums(const float* __restrict__ drbf, const float* __restrict__ dr1pre,
+                                                        const float* __restrict__ dist, float* __restrict__ out_b2,
+                                                        float* __restrict__ out_w0, float* __restrict__ out_b0, int E) {
+  __shared__ float sh[3][8][32];
+  const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int r0 = blockIdx.x * 256, r1 = min(E, r0 + 256);
+  float s2 = 0.f, sw = 0.f, sb = 0.f;
+  for (int r = r0 + grp; r < r1; r += 8) {
+    const float d1 = dr1pre[(size_t)r * 32 + c];
+    s2 += drbf[(size_t)r * 32 + c];
+    sw += d1 * dist[r];
+    sb += d1;
+  }
+  sh[0][grp][c] = s2; sh[1][grp][c] = sw; sh[2][grp][c] = sb;
+  __syncthreads();
+  if (threadIdx.x < 96) {
+    const int which = threadIdx.x >> 5;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += sh[which][g][c];
+    atomicAdd((which == 0 ? out_b2 : which == 1 ? out_w0 : out_b0) + c, t);
+  }
+}
+
 // LayerNorm backward over 256-wide rows, one wave per row, 8 rows per wave.
 //   v = pre(u), xh = (v - mean) rstd, y = post(xh g + b)
 //   dy_total = dy[row] (+ dy2[idx[row]])
