@@ -148,8 +148,9 @@ static void ln_bwd(const float* u, int ldu, const float* gamma, const float* bet
                    const float* dy2, int ld2, const int32_t* idx, float* du, int ldo, float* dgamma, float* dbeta,
                    int M, hipStream_t s) {
   if (M <= 0) return;
-  hipLaunchKernelGGL((k_ln_bwd<PRE, POST>), dim3(ceil_div(M, 32)), dim3(256), 0, s, u, ldu, gamma, beta, eps, dy, ldy, dy2,
-                     ld2, idx, du, ldo, dgamma, dbeta, M);
+  const int rpw = M > 16384 ? 16 : 8;   // measured on edge-row calls: 8 / 16 / 32 / 64 rows per wave -> 95 / 75 / 95 / 150 us
+  hipLaunchKernelGGL((k_ln_bwd<PRE, POST>), dim3(ceil_div(M, 4 * rpw)), dim3(256), 0, s, u, ldu, gamma, beta, eps, dy, ldy, dy2,
+                     ld2, idx, du, ldo, dgamma, dbeta, M, rpw);
 }
 
 __global__ void k_gelu_elem(const float* __restrict__ in, float* __restrict__ out, int64_t n) {
@@ -300,7 +301,7 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
       float* e256b = T(L.e256b);
       float* dpre = T(L.e256c);
       // coordinate gate
-      hipLaunchKernelGGL(k_coord_bwd, dim3(1024), dim3(256), 0, s, G, g->src, g->dst, A(F.rel[l]), A(F.cw[l]),
+      hipLaunchKernelGGL(k_coord_bwd, dim3(512), dim3(256), 0, s, G, g->src, g->dst, A(F.rel[l]), A(F.cw[l]),
                          A(F.hc_pre[l]), w[W_E3(l, E3_CN2_W)], drel, dhc, gr[W_E3(l, E3_CN2_W)], gr[W_E3(l, E3_CN2_B)], E);
       if (!gemm_dw<8>(dhc, 128, 128, A(F.msg[l]), 256, 256, E, gr[W_E3(l, E3_CN0_W)], 256, s, gr[W_E3(l, E3_CN0_B)]))
         colsum(dhc, 128, E, 128, nullptr, gr[W_E3(l, E3_CN0_B)], s);

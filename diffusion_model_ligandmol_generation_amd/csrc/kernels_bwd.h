@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void k_radial_colsums(const float* __restrict_
   }
 }
 
-// LayerNorm backward over 256-wide rows, one wave per row, 8 rows per wave.
+// LayerNorm backward over 256-wide rows, one wave per row, `rpw` rows per wave (each workgroup ends with
+// 512 atomics into the same dgamma / dbeta addresses, which serialise in L2: large M takes more rows
+// per wave so that the atomic chain stays shorter than the streaming time).
 //   v = pre(u), xh = (v - mean) rstd, y = post(xh g + b)
 //   dy_total = dy[row] (+ dy2[idx[row]])
 // writes du[row] and accumulates dgamma / dbeta.
@@ -89,14 +91,14 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ u, int
                                                 const float* __restrict__ dy, int ldy,
                                                 const float* __restrict__ dy2, int ld2, const int32_t* __restrict__ idx,
                                                 float* __restrict__ du, int ldo, float* __restrict__ dgamma,
-                                                float* __restrict__ dbeta, int M) {
+                                                float* __restrict__ dbeta, int M, int rpw) {
   __shared__ float sh[2][4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + lane * 4);
   const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + lane * 4);
   f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
-  const int rbase = (blockIdx.x * 4 + wave) * 8;
-  for (int rr = 0; rr < 8; ++rr) {
+  const int rbase = (blockIdx.x * 4 + wave) * rpw;
+  for (int rr = 0; rr < rpw; ++rr) {
     const int row = rbase + rr;
     if (row >= M) break;
     const f32x4 uu = *reinterpret_cast<const f32x4*>(u + (size_t)row * ldu + lane * 4);
@@ -424,28 +426,52 @@ __global__ __launch_bounds__(256) void k_coord_bwd(const float* __restrict__ G, 
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
   const float w2a = w2[lane], w2b = w2[lane + 64];
   float acc_a = 0.f, acc_b = 0.f, acc_b2 = 0.f;
-  for (int e = gw; e < E; e += nw) {
-    const int s = src[e], d = dst[e];
-    float dcw = 0.f, dw[3];
+  // Four edges per pass, every load of the pass issued before its first store: an edge is a chain of
+  // dependent loads (indices -> G rows), and a store through drel / dhc_pre would otherwise fence the
+  // next edge's loads behind it.
+  for (int e0 = gw * 4; e0 < E; e0 += nw * 4) {
+    float dwv[4][3], relv[4][3], cwv[4], ha[4], hb[4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      dw[c] = 0.1f * (G[(size_t)d * 3 + c] - G[(size_t)s * 3 + c]);
-      dcw += dw[c] * rel[(size_t)e * 4 + c];
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u < E ? e0 + u : E - 1;
+      const int s = src[e], d = dst[e];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dwv[u][c] = 0.1f * (G[(size_t)d * 3 + c] - G[(size_t)s * 3 + c]);
+        relv[u][c] = rel[(size_t)e * 4 + c];
+      }
+      cwv[u] = cw[e];
+      ha[u] = hc_pre[(size_t)e * 128 + lane];
+      hb[u] = hc_pre[(size_t)e * 128 + lane + 64];
     }
-    const float c_w = cw[e];
-    const float ds = dcw * (1.0f - c_w * c_w);
-    if (lane < 3) drel[(size_t)e * 4 + lane] = dw[lane] * c_w;
-    if (lane == 3) drel[(size_t)e * 4 + 3] = 0.f;
-    const float ha = hc_pre[(size_t)e * 128 + lane], hb = hc_pre[(size_t)e * 128 + lane + 64];
-    dhc_pre[(size_t)e * 128 + lane] = ds * w2a * silu_grad(ha);
-    dhc_pre[(size_t)e * 128 + lane + 64] = ds * w2b * silu_grad(hb);
-    acc_a += ds * silu(ha);
-    acc_b += ds * silu(hb);
-    acc_b2 += ds;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u;
+      if (e >= E) break;
+      const float dcw = (dwv[u][0] * relv[u][0] + dwv[u][1] * relv[u][1]) + dwv[u][2] * relv[u][2];
+      const float c_w = cwv[u];
+      const float ds = dcw * (1.0f - c_w * c_w);
+      if (lane < 3) drel[(size_t)e * 4 + lane] = dwv[u][lane == 0 ? 0 : lane == 1 ? 1 : 2] * c_w;
+      if (lane == 3) drel[(size_t)e * 4 + 3] = 0.f;
+      dhc_pre[(size_t)e * 128 + lane] = ds * w2a * silu_grad(ha[u]);
+      dhc_pre[(size_t)e * 128 + lane + 64] = ds * w2b * silu_grad(hb[u]);
+      acc_a += ds * silu(ha[u]);
+      acc_b += ds * silu(hb[u]);
+      acc_b2 += ds;
+    }
   }
-  atomicAdd(dw2 + lane, acc_a);
-  atomicAdd(dw2 + lane + 64, acc_b);
-  if (lane == 0) atomicAdd(db2, acc_b2);
+  // one set of atomics per workgroup: thousands of waves adding into the same 129 addresses serialise
+  // in L2 (the kernel was bound by exactly that)
+  __shared__ float red[4][129];
+  const int wave = threadIdx.x >> 6;
+  red[wave][lane] = acc_a;
+  red[wave][lane + 64] = acc_b;
+  if (lane == 0) red[wave][128] = acc_b2;
+  __syncthreads();
+  if (threadIdx.x < 129) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    atomicAdd(threadIdx.x < 128 ? dw2 + threadIdx.x : db2, t);
+  }
 }
 
 // dP[n, 0:256] = sum over edges LEAVING n of dpre[e];  dP[n, 256:512] = sum over edges
