@@ -225,7 +225,7 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
     float* t256b = T(L.n256b);
     float* t256c = T(L.n256c);
     // x2 = x1 + gate_mlp * (ffh W3^T + b)
-    hipLaunchKernelGGL(k_gate_bwd, dim3(nb4B), dim3(256), 0, s, dxa, A(F.fproj[l]), mod, 1536, 1280, g->mol_ptr, B, t256b, dmod);
+    hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dxa, A(F.fproj[l]), mod, 1536, 1280, g->mol_ptr, B, t256b, dmod);
     if (!gemm_dw<8>(t256b, 256, 256, A(F.ffh[l]), 1024, 1024, N, gr[W_DIT(l, DIT_FF3_W)], 1024, s, gr[W_DIT(l, DIT_FF3_B)]))
       colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_FF3_B)], s);
     float* dffh = T(L.n1024);
@@ -234,10 +234,10 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
     if (!gemm_dw<8>(dffh, 1024, 1024, A(F.xn2[l]), 256, 256, N, gr[W_DIT(l, DIT_FF0_W)], 256, s, gr[W_DIT(l, DIT_FF0_B)]))
       colsum(dffh, 1024, N, 1024, nullptr, gr[W_DIT(l, DIT_FF0_B)], s);
     gemm_dx<8, MUL_NONE, false>(dffh, 1024, N, 1024, w[W_DIT(l, DIT_FF0_W)], 256, 256, t256c, 256, nullptr, 0, s);
-    hipLaunchKernelGGL(k_lnmod_bwd, dim3(nb4B), dim3(256), 0, s, A(F.x1[l]), t256c, dxa, mod, 1536, 768, 1024,
+    hipLaunchKernelGGL(k_lnmod_bwd, dim3(B), dim3(256), 0, s, A(F.x1[l]), t256c, dxa, mod, 1536, 768, 1024,
                        g->mol_ptr, B, dxa, dmod);
     // x1 = x_in + gate_msa * (att Wo^T + b)
-    hipLaunchKernelGGL(k_gate_bwd, dim3(nb4B), dim3(256), 0, s, dxa, A(F.oproj[l]), mod, 1536, 512, g->mol_ptr, B, t256b, dmod);
+    hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dxa, A(F.oproj[l]), mod, 1536, 512, g->mol_ptr, B, t256b, dmod);
     if (!gemm_dw<8>(t256b, 256, 256, A(F.att[l]), 256, 256, N, gr[W_DIT(l, DIT_OUT_W)], 256, s, gr[W_DIT(l, DIT_OUT_B)]))
       colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_OUT_B)], s);
     gemm_dx<8, MUL_NONE, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_OUT_W)], 256, 256, t256c, 256, nullptr, 0, s);
@@ -270,7 +270,7 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
     if (!gemm_dw<8>(dqkv, 768, 768, A(F.xn1[l]), 256, 256, N, gr[W_DIT(l, DIT_INP_W)], 256, s, gr[W_DIT(l, DIT_INP_B)]))
       colsum(dqkv, 768, N, 768, nullptr, gr[W_DIT(l, DIT_INP_B)], s);
     gemm_dx<8, MUL_NONE, false>(dqkv, 768, N, 768, w[W_DIT(l, DIT_INP_W)], 256, 256, t256c, 256, nullptr, 0, s);
-    hipLaunchKernelGGL(k_lnmod_bwd, dim3(nb4B), dim3(256), 0, s, x_in, t256c, dxa, mod, 1536, 0, 256, g->mol_ptr, B,
+    hipLaunchKernelGGL(k_lnmod_bwd, dim3(B), dim3(256), 0, s, x_in, t256c, dxa, mod, 1536, 0, 256, g->mol_ptr, B,
                        dxa, dmod);
   }
 

@@ -135,26 +135,30 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ u, int
   atomicAdd(dbeta + t, (sh[1][0][t] + sh[1][1][t]) + (sh[1][2][t] + sh[1][3][t]));
 }
 
-// Gated residual backward (model1.py:295 / :300), one wave per molecule:
+// Gated residual backward (model1.py:295 / :300), one WORKGROUP per molecule (its atoms strided over the
+// four waves, per-molecule sums combined through LDS in a fixed order: no atomics, bit-reproducible):
 //   dproj[n] = dx[n] * gate[mol];   dgate[mol] = sum_n dx[n] * proj[n]
 __global__ __launch_bounds__(256) void k_gate_bwd(const float* __restrict__ dx, const float* __restrict__ proj,
                                                   const float* __restrict__ mod, int mod_stride, int gate_off,
                                                   const int32_t* __restrict__ mol_ptr, int B, float* __restrict__ dproj,
                                                   float* __restrict__ dmod) {
-  const int lane = threadIdx.x & 63;
-  const int mol = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (mol >= B) return;
+  __shared__ float sh[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mol = blockIdx.x;
   const f32x4 gate = *reinterpret_cast<const f32x4*>(mod + (size_t)mol * mod_stride + gate_off + lane * 4);
   f32x4 dgate = {0.f, 0.f, 0.f, 0.f};
-  for (int a = mol_ptr[mol]; a < mol_ptr[mol + 1]; ++a) {
+  for (int a = mol_ptr[mol] + wave; a < mol_ptr[mol + 1]; a += 4) {
     const f32x4 d = *reinterpret_cast<const f32x4*>(dx + (size_t)a * 256 + lane * 4);
     dgate += d * *reinterpret_cast<const f32x4*>(proj + (size_t)a * 256 + lane * 4);
     *reinterpret_cast<f32x4*>(dproj + (size_t)a * 256 + lane * 4) = d * gate;
   }
-  *reinterpret_cast<f32x4*>(dmod + (size_t)mol * 1536 + gate_off + lane * 4) = dgate;
+  *reinterpret_cast<f32x4*>(&sh[wave][lane * 4]) = dgate;
+  __syncthreads();
+  const int t = threadIdx.x;
+  dmod[(size_t)mol * 1536 + gate_off + t] = (sh[0][t] + sh[1][t]) + (sh[2][t] + sh[3][t]);
 }
 
-// Modulated pre-norm backward (model1.py:293 / :298), one wave per molecule:
+// Modulated pre-norm backward (model1.py:293 / :298), one workgroup per molecule (as k_gate_bwd):
 //   xn = LN(x)(1 + scale) + shift  ->  dx_out[n] = dres[n] + LNbwd(dxn[n] (1 + scale)),
 //   dshift[mol] = sum_n dxn[n],  dscale[mol] = sum_n dxn[n] * xhat[n]
 __global__ __launch_bounds__(256) void k_lnmod_bwd(const float* __restrict__ x, const float* __restrict__ dxn,
@@ -162,12 +166,12 @@ __global__ __launch_bounds__(256) void k_lnmod_bwd(const float* __restrict__ x, 
                                                    int mod_stride, int shift_off, int scale_off,
                                                    const int32_t* __restrict__ mol_ptr, int B,
                                                    float* __restrict__ dx_out, float* __restrict__ dmod) {
-  const int lane = threadIdx.x & 63;
-  const int mol = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (mol >= B) return;
+  __shared__ float sh[2][4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mol = blockIdx.x;
   const f32x4 sc1 = 1.0f + *reinterpret_cast<const f32x4*>(mod + (size_t)mol * mod_stride + scale_off + lane * 4);
   f32x4 dsh = {0.f, 0.f, 0.f, 0.f}, dsc = {0.f, 0.f, 0.f, 0.f};
-  for (int a = mol_ptr[mol]; a < mol_ptr[mol + 1]; ++a) {
+  for (int a = mol_ptr[mol] + wave; a < mol_ptr[mol + 1]; a += 4) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)a * 256 + lane * 4);
     const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
     const f32x4 d = v - mean;
@@ -183,8 +187,12 @@ __global__ __launch_bounds__(256) void k_lnmod_bwd(const float* __restrict__ x, 
     if (dres != nullptr) o += *reinterpret_cast<const f32x4*>(dres + (size_t)a * 256 + lane * 4);
     *reinterpret_cast<f32x4*>(dx_out + (size_t)a * 256 + lane * 4) = o;
   }
-  *reinterpret_cast<f32x4*>(dmod + (size_t)mol * 1536 + shift_off + lane * 4) = dsh;
-  *reinterpret_cast<f32x4*>(dmod + (size_t)mol * 1536 + scale_off + lane * 4) = dsc;
+  *reinterpret_cast<f32x4*>(&sh[0][wave][lane * 4]) = dsh;
+  *reinterpret_cast<f32x4*>(&sh[1][wave][lane * 4]) = dsc;
+  __syncthreads();
+  const int t = threadIdx.x;
+  dmod[(size_t)mol * 1536 + shift_off + t] = (sh[0][0][t] + sh[0][1][t]) + (sh[0][2][t] + sh[0][3][t]);
+  dmod[(size_t)mol * 1536 + scale_off + t] = (sh[1][0][t] + sh[1][1][t]) + (sh[1][2][t] + sh[1][3][t]);
 }
 
 // Attention backward for one (molecule, head) per wave (blockDim.x / 64 heads per workgroup).
