@@ -57,6 +57,19 @@ __global__ __launch_bounds__(256) void k_transpose_block(const float* __restrict
 // Scratch for the transposed weight block (set per ligdiff_backward call from its workspace).
 static thread_local float* g_wt_scratch = nullptr;
 
+// dW[nout, 32] += dY[rows, nout]^T X[rows, 32]  (k_dw_k32: nout a multiple of 32, long reductions)
+static void gemm_dw_k32(const float* dY, int lddy, int nout, const float* X, int ldx, int rows, float* dW, int lddw,
+                        hipStream_t s) {
+  if (rows <= 0) return;
+  const int n_tiles = nout / 32;
+  int slices = ceil_div(2048, n_tiles);                 // ~2048 waves in flight
+  int rps = (int)align_up(ceil_div(rows, slices), 8);
+  if (rps < 64) rps = 64;
+  slices = ceil_div(rows, rps);
+  hipLaunchKernelGGL(k_dw_k32, dim3(ceil_div(n_tiles * slices, 4)), dim3(256), 0, s, dY, lddy, nout, X, ldx, rows, rps, dW,
+                     lddw);
+}
+
 // C[M, ncols] (+)= dY[M, K] * W[K, ncols]  [* act'(pre)]     (W is the forward weight [out=K, in])
 // When the shape allows (ncols a multiple of 256, K of 16, aligned rows) the weight block is
 // transposed into scratch - a few hundred KB - and the product runs on the forward pass's LDS-DMA
@@ -316,14 +329,14 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
       // pre = Pa[src] + Pb[dst] + Wc rbf + b1.  The bias gradient sum_e dpre[e] equals the column sum of
       // the per-destination gather dP[:, 256:512] (every edge has exactly one destination atom), which
       // the weight-gradient GEMM on that block produces in the same pass (N rows instead of E).
-      gemm_dw<4>(dpre, 256, 256, A(F.rbf[l]), 32, 32, E, dW1 + 512, 544, s);
+      gemm_dw_k32(dpre, 256, 256, A(F.rbf[l]), 32, E, dW1 + 512, 544, s);
       float* drbf = T(L.e32a);
       gemm_dx<4, MUL_NONE, false>(dpre, 256, E, 256, W1 + 512, 544, 32, drbf, 32, nullptr, 0, s);
       float* dr1pre = T(L.e32b);
       float* r1 = T(L.e32c);
       hipLaunchKernelGGL(k_radial_bwd, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, A(F.r1pre[l]), A(F.dist[l]),
                          A(F.rel[l]), w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB2_W)], drel, dr1pre, r1, E);
-      gemm_dw<4>(drbf, 32, 32, r1, 32, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s);   // 32-wide: register-staged kernel, no bias sum
+      gemm_dw_k32(drbf, 32, 32, r1, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s);
       hipLaunchKernelGGL(k_radial_colsums, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, dr1pre, A(F.dist[l]),
                          gr[W_E3(l, E3_RB2_B)], gr[W_E3(l, E3_RB0_W)], gr[W_E3(l, E3_RB0_B)], E);
       float* dP = T(L.n512);
