@@ -57,17 +57,17 @@ __global__ __launch_bounds__(256) void k_transpose_block(const float* __restrict
 // Scratch for the transposed weight block (set per ligdiff_backward call from its workspace).
 static thread_local float* g_wt_scratch = nullptr;
 
-// dW[nout, 32] += dY[rows, nout]^T X[rows, 32]  (k_dw_k32: nout a multiple of 32, long reductions)
-static void gemm_dw_k32(const float* dY, int lddy, int nout, const float* X, int ldx, int rows, float* dW, int lddw,
-                        hipStream_t s) {
+// dW[nout, kin] += dY[rows, nout]^T X[rows, kin] (+ db) for narrow / unaligned shapes (k_dw_direct)
+static void gemm_dw_direct(const float* dY, int lddy, int nout, const float* X, int ldx, int kin, int rows, float* dW,
+                           int lddw, hipStream_t s, float* db = nullptr) {
   if (rows <= 0) return;
-  const int n_tiles = nout / 32;
-  int slices = ceil_div(2048, n_tiles);                 // ~2048 waves in flight
-  int rps = (int)align_up(ceil_div(rows, slices), 8);
-  if (rps < 64) rps = 64;
+  const int tiles = ceil_div(nout, 32) * ceil_div(kin, 32);
+  int slices = ceil_div(2048, tiles);                   // ~2048 waves in flight
+  int rps = (int)align_up(ceil_div(rows, slices), 32);
+  if (rps < 128) rps = 128;
   slices = ceil_div(rows, rps);
-  hipLaunchKernelGGL(k_dw_k32, dim3(ceil_div(n_tiles * slices, 4)), dim3(256), 0, s, dY, lddy, nout, X, ldx, rows, rps, dW,
-                     lddw);
+  hipLaunchKernelGGL(k_dw_direct, dim3(ceil_div(tiles * slices, 4)), dim3(256), 0, s, dY, lddy, nout, X, ldx, kin, rows, rps,
+                     dW, lddw, db);
 }
 
 // C[M, ncols] (+)= dY[M, K] * W[K, ncols]  [* act'(pre)]     (W is the forward weight [out=K, in])
@@ -201,8 +201,7 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
   float* dyh = T(L.n512);
   gemm_dx<8, MUL_NONE, false>(d_atom, LD_A, N, LD_A, w[W_HEAD(0, HEAD_W3)], 256, 256, dyh, 512, nullptr, 0, s);
   hipLaunchKernelGGL(k_small_dx<3>, dim3(nb4N), dim3(256), 0, s, d_pos, w[W_HEAD(1, HEAD_W3)], dyh, 512, 256, N);
-  if (!gemm_dw<8>(d_atom, LD_A, LD_A, A(F.yh), 512, 256, N, gr[W_HEAD(0, HEAD_W3)], 256, s, gr[W_HEAD(0, HEAD_B3)]))
-    colsum(d_atom, LD_A, N, LD_A, nullptr, gr[W_HEAD(0, HEAD_B3)], s);
+  gemm_dw_direct(d_atom, LD_A, LD_A, A(F.yh), 512, 256, N, gr[W_HEAD(0, HEAD_W3)], 256, s, gr[W_HEAD(0, HEAD_B3)]);
   hipLaunchKernelGGL(k_small_dw<3>, dim3(ceil_div(N, 128)), dim3(256), 0, s, d_pos, A(F.yh), 512, 256,
                      gr[W_HEAD(1, HEAD_W3)], gr[W_HEAD(1, HEAD_B3)], N);
   for (int h = 0; h < 2; ++h) {
@@ -329,14 +328,14 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
       // pre = Pa[src] + Pb[dst] + Wc rbf + b1.  The bias gradient sum_e dpre[e] equals the column sum of
       // the per-destination gather dP[:, 256:512] (every edge has exactly one destination atom), which
       // the weight-gradient GEMM on that block produces in the same pass (N rows instead of E).
-      gemm_dw_k32(dpre, 256, 256, A(F.rbf[l]), 32, E, dW1 + 512, 544, s);
+      gemm_dw_direct(dpre, 256, 256, A(F.rbf[l]), 32, 32, E, dW1 + 512, 544, s);
       float* drbf = T(L.e32a);
       gemm_dx<4, MUL_NONE, false>(dpre, 256, E, 256, W1 + 512, 544, 32, drbf, 32, nullptr, 0, s);
       float* dr1pre = T(L.e32b);
       float* r1 = T(L.e32c);
       hipLaunchKernelGGL(k_radial_bwd, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, A(F.r1pre[l]), A(F.dist[l]),
                          A(F.rel[l]), w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB2_W)], drel, dr1pre, r1, E);
-      gemm_dw_k32(drbf, 32, 32, r1, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s);
+      gemm_dw_direct(drbf, 32, 32, r1, 32, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s);
       hipLaunchKernelGGL(k_radial_colsums, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, dr1pre, A(F.dist[l]),
                          gr[W_E3(l, E3_RB2_B)], gr[W_E3(l, E3_RB0_W)], gr[W_E3(l, E3_RB0_B)], E);
       float* dP = T(L.n512);
@@ -356,8 +355,7 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
     float* du = T(L.n256b);
     ln_bwd<0, 1>(A(F.ua), 256, w[W_ATOM_G], w[W_ATOM_BE], 1e-5f, dxa, 256, nullptr, 0, nullptr, du, 256, gr[W_ATOM_G],
                  gr[W_ATOM_BE], N, s);
-    if (!gemm_dw<4>(du, 256, 256, x, LD_A, LD_A, N, gr[W_ATOM_W], LD_A, s, gr[W_ATOM_B]))
-      colsum(du, 256, N, 256, nullptr, gr[W_ATOM_B], s);
+    gemm_dw_direct(du, 256, 256, x, LD_A, LD_A, N, gr[W_ATOM_W], LD_A, s, gr[W_ATOM_B]);
     float* up = T(L.n256c);
     float* dup = T(L.n256d);
     hipLaunchKernelGGL(k_pos_embed_pre, dim3(nb4N), dim3(256), 0, s, pos, w[W_POS_W], w[W_POS_B], up, N);

@@ -52,48 +52,65 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ Y, int
   atomicAdd(out + c, s);
 }
 
-// Weight gradient with a 32-wide input and a long reduction (the radial-basis columns of the first edge
-// linear, the second radial linear):  dW[n, k] += sum_e dY[e, n] X[e, k],  k < 32, nout a multiple of 32.
-// One wave per (32-row n tile, slice of `rows_per_slice` reduction rows), fp32 MFMA with both operands
-// loaded straight from global memory: for step (e, e + 1) lane (i, h) holds dY[e + h, n0 + i] and
-// X[e + h, i] - two coalesced 128-B row segments per half-wave.  4 waves per workgroup.
-__global__ __launch_bounds__(256) void k_dw_k32(const float* __restrict__ dY, int lddy, int nout,
-                                                const float* __restrict__ X, int ldx, int rows, int rows_per_slice,
-                                                float* __restrict__ dW, int lddw) {
+// Weight gradient for shapes the LDS-DMA kernel cannot take (widths 32 / 119, unaligned leading
+// dimensions) with a long reduction:  dW[n, k] += sum_e dY[e, n] X[e, k]  (+ db[n] += sum_e dY[e, n]).
+// One wave per (32-row n tile, 32-column k tile, slice of `rows_per_slice` reduction rows), fp32 MFMA with
+// both operands loaded straight from global memory: for step (e, e + 1) lane (i, h) holds
+// dY[e + h, n0 + i] and X[e + h, k0 + i] - two coalesced 128-B row segments per half-wave, no alignment
+// needed.  Columns beyond nout / kin read as zero.  4 waves per workgroup.
+__global__ __launch_bounds__(256) void k_dw_direct(const float* __restrict__ dY, int lddy, int nout,
+                                                   const float* __restrict__ X, int ldx, int kin, int rows,
+                                                   int rows_per_slice, float* __restrict__ dW, int lddw,
+                                                   float* __restrict__ db) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n_tiles = nout >> 5;
+  const int n_tiles = (nout + 31) >> 5, k_tiles = (kin + 31) >> 5;
   const int item = blockIdx.x * 4 + wave;
-  const int tile = item % n_tiles, slice = item / n_tiles;
+  const int tile = item % (n_tiles * k_tiles), slice = item / (n_tiles * k_tiles);
+  const int nt = tile / k_tiles, kt = tile % k_tiles;
   const int e0 = slice * rows_per_slice, e1 = min(rows, e0 + rows_per_slice);
   if (e0 >= e1) return;
   const int i = lane & 31, h = lane >> 5;
-  const float* yp = dY + (size_t)tile * 32 + i;
-  const float* xp = X + i;
+  const bool n_ok = nt * 32 + i < nout, k_ok = kt * 32 + i < kin;
+  const float* yp = dY + (n_ok ? nt * 32 + i : 0);
+  const float* xp = X + (k_ok ? kt * 32 + i : 0);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
   int e = e0;
-  for (; e + 8 <= e1; e += 8) {   // four MFMA steps per pass, their eight loads issued together
-    float a[4], b[4];
+  for (; e + 32 <= e1; e += 32) {   // sixteen MFMA steps per pass, their 32 loads issued together (latency-bound otherwise)
+    float a[16], b[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 16; ++u) {
       a[u] = yp[(size_t)(e + 2 * u + h) * lddy];
       b[u] = xp[(size_t)(e + 2 * u + h) * ldx];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    for (int u = 0; u < 16; ++u) {
+      a[u] = n_ok ? a[u] : 0.f;
+      b[u] = k_ok ? b[u] : 0.f;
+      bsum += a[u];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
   }
   for (; e < e1; e += 2) {
     const bool ok = e + h < e1;
-    const float a = ok ? yp[(size_t)(e + h) * lddy] : 0.f;
-    const float b = ok ? xp[(size_t)(e + h) * ldx] : 0.f;
+    const float a = (ok && n_ok) ? yp[(size_t)(e + h) * lddy] : 0.f;
+    const float b = (ok && k_ok) ? xp[(size_t)(e + h) * ldx] : 0.f;
+    bsum += a;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
   }
   // accumulator: column = k (lane & 31), row = n offset (r & 3) + 8 (r >> 2) + 4 h
+  if (k_ok) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int n = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    atomicAdd(dW + (size_t)n * lddw + i, acc[r]);
+    for (int r = 0; r < 16; ++r) {
+      const int n = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (n < nout) atomicAdd(dW + (size_t)n * lddw + kt * 32 + i, acc[r]);
+    }
+  }
+  if (db != nullptr && kt == 0) {
+    bsum += __shfl_xor(bsum, 32);
+    if (h == 0 && n_ok) atomicAdd(db + nt * 32 + i, bsum);
   }
 }
 
