@@ -160,34 +160,47 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ u, int
   const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + lane * 4);
   f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
   const int rbase = (blockIdx.x * 4 + wave) * rpw;
-  for (int rr = 0; rr < rpw; ++rr) {
-    const int row = rbase + rr;
-    if (row >= M) break;
-    const f32x4 uu = *reinterpret_cast<const f32x4*>(u + (size_t)row * ldu + lane * 4);
-    f32x4 v;
+  // rows in groups of four, the group's loads issued before any of its arithmetic (a row is otherwise a
+  // serial chain of one memory latency and five wave reductions)
+  for (int rr = 0; rr < rpw; rr += 4) {
+    f32x4 uu4[4], dy4[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = PRE_ACT == 1 ? gelu_exact(uu[i]) : uu[i];
-    const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
-    const f32x4 d = v - mean;
-    const float rstd = 1.0f / sqrtf(wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f) + eps);
-    const f32x4 xh = d * rstd;
-    f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + (size_t)row * ldy + lane * 4);
-    if (dy2 != nullptr) dyv += *reinterpret_cast<const f32x4*>(dy2 + (size_t)idx[row] * ld2 + lane * 4);
-    if (POST_ACT == 1) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dyv[i] *= gelu_exact_grad(xh[i] * g[i] + bt[i]);
+    for (int q = 0; q < 4; ++q) {
+      const int row = rbase + rr + q;
+      const int rc = row < M ? row : M - 1;
+      uu4[q] = *reinterpret_cast<const f32x4*>(u + (size_t)rc * ldu + lane * 4);
+      dy4[q] = *reinterpret_cast<const f32x4*>(dy + (size_t)rc * ldy + lane * 4);
+      if (dy2 != nullptr) dy4[q] += *reinterpret_cast<const f32x4*>(dy2 + (size_t)idx[rc] * ld2 + lane * 4);
     }
-    dg += dyv * xh;
-    db += dyv;
-    const f32x4 dxh = dyv * g;
-    const float m1 = wave_sum((dxh[0] + dxh[1]) + (dxh[2] + dxh[3])) * (1.0f / 256.0f);
-    const float m2 = wave_sum((dxh[0] * xh[0] + dxh[1] * xh[1]) + (dxh[2] * xh[2] + dxh[3] * xh[3])) * (1.0f / 256.0f);
-    f32x4 dv = (dxh - m1 - xh * m2) * rstd;
-    if (PRE_ACT == 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dv[i] *= gelu_exact_grad(uu[i]);
+    for (int q = 0; q < 4; ++q) {
+      const int row = rbase + rr + q;
+      if (row >= M || rr + q >= rpw) break;
+      const f32x4 uu = uu4[q];
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = PRE_ACT == 1 ? gelu_exact(uu[i]) : uu[i];
+      const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+      const f32x4 d = v - mean;
+      const float rstd = 1.0f / sqrtf(wave_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) * (1.0f / 256.0f) + eps);
+      const f32x4 xh = d * rstd;
+      f32x4 dyv = dy4[q];
+      if (POST_ACT == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dyv[i] *= gelu_exact_grad(xh[i] * g[i] + bt[i]);
+      }
+      dg += dyv * xh;
+      db += dyv;
+      const f32x4 dxh = dyv * g;
+      const float m1 = wave_sum((dxh[0] + dxh[1]) + (dxh[2] + dxh[3])) * (1.0f / 256.0f);
+      const float m2 = wave_sum((dxh[0] * xh[0] + dxh[1] * xh[1]) + (dxh[2] * xh[2] + dxh[3] * xh[3])) * (1.0f / 256.0f);
+      f32x4 dv = (dxh - m1 - xh * m2) * rstd;
+      if (PRE_ACT == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dv[i] *= gelu_exact_grad(uu[i]);
+      }
+      *reinterpret_cast<f32x4*>(du + (size_t)row * ldo + lane * 4) = dv;
     }
-    *reinterpret_cast<f32x4*>(du + (size_t)row * ldo + lane * 4) = dv;
   }
   *reinterpret_cast<f32x4*>(&sh[0][wave][lane * 4]) = dg;
   *reinterpret_cast<f32x4*>(&sh[1][wave][lane * 4]) = db;
