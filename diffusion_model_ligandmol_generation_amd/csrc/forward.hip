@@ -456,7 +456,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   const int max_n = g->max_mol_atoms;
   const float* x_in = h_in;
   PB("dit0.ln_mod");
-  hipLaunchKernelGGL(k_ln_mod, dim3(ceil_div(N, 4)), dim3(256), 0, s, x_in, F(L.mod[0]), mstride, 0, 256,
+  hipLaunchKernelGGL(k_ln_mod, dim3(ceil_div(N, 16)), dim3(256), 0, s, x_in, F(L.mod[0]), mstride, 0, 256,
                      g->atom_mol, F(L.xn1[0]), N);
   PE();
   for (int l = 0; l < 3; ++l) {
@@ -549,7 +549,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     PE();
   }
   PB("head.pos");
-  hipLaunchKernelGGL(k_head_small<3>, dim3(ceil_div(N, 4)), dim3(256), 0, s, F(L.yh), 512, 256, w[W_HEAD(1, HEAD_W3)],
+  hipLaunchKernelGGL(k_head_small<3>, dim3(ceil_div(N, 16)), dim3(256), 0, s, F(L.yh), 512, 256, w[W_HEAD(1, HEAD_W3)],
                      w[W_HEAD(1, HEAD_B3)], F(L.pos_upd), pos_pred, N);
   PE();
   if (!(flags & LIGDIFF_FWD_SKIP_PROP_HEAD)) {
@@ -561,7 +561,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     e.M = B; e.eps = 1e-5f; e.C = F(L.ph); e.ldc = 256; e.pre_out = S(L.u_ph);
     e.bias[0] = w[W_HEAD(2, HEAD_B0)]; e.gamma[0] = w[W_HEAD(2, HEAD_G)]; e.beta[0] = w[W_HEAD(2, HEAD_BE)];
     launch_gemm_plain<8>(gc, F(L.pooled), 256, e, 1, s);
-    hipLaunchKernelGGL(k_head_small<15>, dim3(ceil_div(B, 4)), dim3(256), 0, s, F(L.ph), 256, 0, w[W_HEAD(2, HEAD_W3)],
+    hipLaunchKernelGGL(k_head_small<15>, dim3(ceil_div(B, 16)), dim3(256), 0, s, F(L.ph), 256, 0, w[W_HEAD(2, HEAD_W3)],
                        w[W_HEAD(2, HEAD_B3)], (const float*)nullptr, prop_pred, B);
   }
   LD_CHECK_LAUNCH();

@@ -218,21 +218,34 @@ __global__ __launch_bounds__(256) void k_ln_mod(const float* __restrict__ x, con
                                                 int mod_stride, int shift_off, int scale_off,
                                                 const int32_t* __restrict__ atom_mol,
                                                 float* __restrict__ xn, int N) {
+  // four rows per wave, all loads first: a wave per row leaves one KiB in flight per wave and the launch
+  // of ~30 000 short waves is then the cost
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= N) return;
-  const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)row * 256 + lane * 4);
-  const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
-  const f32x4 dlt = v - mean;
-  const float var = wave_sum((dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3])) * (1.0f / 256.0f);
-  const float rstd = 1.0f / sqrtf(var + 1e-6f);
-  const float* m = mod + (size_t)atom_mol[row] * mod_stride;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(m + scale_off + lane * 4);
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(m + shift_off + lane * 4);
-  f32x4 o;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  if (row0 >= N) return;
+  f32x4 v4[4], sc4[4], sh4[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (dlt[i] * rstd) * (1.0f + sc[i]) + sh[i];
-  *reinterpret_cast<f32x4*>(xn + (size_t)row * 256 + lane * 4) = o;
+  for (int q = 0; q < 4; ++q) {
+    const int rc = row0 + q < N ? row0 + q : N - 1;
+    v4[q] = *reinterpret_cast<const f32x4*>(x + (size_t)rc * 256 + lane * 4);
+    const float* m = mod + (size_t)atom_mol[rc] * mod_stride;
+    sc4[q] = *reinterpret_cast<const f32x4*>(m + scale_off + lane * 4);
+    sh4[q] = *reinterpret_cast<const f32x4*>(m + shift_off + lane * 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = row0 + q;
+    if (row >= N) break;
+    const f32x4 v = v4[q];
+    const float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+    const f32x4 dlt = v - mean;
+    const float var = wave_sum((dlt[0] * dlt[0] + dlt[1] * dlt[1]) + (dlt[2] * dlt[2] + dlt[3] * dlt[3])) * (1.0f / 256.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-6f);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (dlt[i] * rstd) * (1.0f + sc4[q][i]) + sh4[q][i];
+    *reinterpret_cast<f32x4*>(xn + (size_t)row * 256 + lane * 4) = o;
+  }
 }
 
 // Per-molecule multi-head attention over the molecule's OWN atoms (8 heads x 32),
@@ -513,17 +526,25 @@ __global__ __launch_bounds__(256) void k_head_small(const float* __restrict__ y,
                                                     const float* __restrict__ W, const float* __restrict__ b,
                                                     const float* __restrict__ add, float* __restrict__ out, int M) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const f32x4 v = *reinterpret_cast<const f32x4*>(y + (size_t)row * ldy + off + lane * 4);
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;   // four rows per wave, loads first
+  if (row0 >= M) return;
+  f32x4 v4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    v4[q] = *reinterpret_cast<const f32x4*>(y + (size_t)(row0 + q < M ? row0 + q : M - 1) * ldy + off + lane * 4);
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
     const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)o * 256 + lane * 4);
-    float s = wave_sum((v[0] * w[0] + v[1] * w[1]) + (v[2] * w[2] + v[3] * w[3]));
-    if (lane == 0) {
-      s += b[o];
-      if (add != nullptr) s += add[(size_t)row * NOUT + o];
-      out[(size_t)row * NOUT + o] = s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = row0 + q;
+      const f32x4 v = v4[q];
+      float s = wave_sum((v[0] * w[0] + v[1] * w[1]) + (v[2] * w[2] + v[3] * w[3]));
+      if (lane == 0 && row < M) {
+        s += b[o];
+        if (add != nullptr) s += add[(size_t)row * NOUT + o];
+        out[(size_t)row * NOUT + o] = s;
+      }
     }
   }
 }
