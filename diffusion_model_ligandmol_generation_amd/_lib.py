@@ -52,6 +52,8 @@ SIGNATURES = {
     "ligdiff_pack_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "ligdiff_pack_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 9
                          + [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ligdiff_pack_csr_static": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 9
+                                + [C.c_void_p]),
     "ligdiff_forward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int]),
     "ligdiff_forward": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -110,17 +110,13 @@ extern "C" size_t ligdiff_pack_workspace_bytes(int64_t n_atoms, int64_t n_edges)
   return (size_t)(4 * (n_atoms + 1)) * sizeof(int32_t);
 }
 
-extern "C" int ligdiff_pack_csr(const int64_t* edge_index, int64_t E, const int64_t* batch, int64_t N, int32_t B,
-                                int32_t* mol_ptr, int32_t* atom_mol, int32_t* dst_ptr, int32_t* src, int32_t* dst,
-                                int32_t* perm, int32_t* src_ptr, int32_t* src_slot, int32_t* status_dev,
-                                void* workspace, size_t workspace_bytes, void* stream) {
-  if (N <= 0 || E < 0 || B <= 0 || !batch || !mol_ptr || !atom_mol || !dst_ptr || !src_ptr || !status_dev || !workspace)
-    return LIGDIFF_ERR_ARG;
-  if (E > 0 && (!edge_index || !src || !dst || !perm || !src_slot)) return LIGDIFF_ERR_ARG;
-  if (N >= (1LL << 30) || E >= (1LL << 30)) return LIGDIFF_ERR_ARG;
-  if (workspace_bytes < ligdiff_pack_workspace_bytes(N, E)) return LIGDIFF_ERR_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
-  int32_t* deg = (int32_t*)workspace;
+// Shared body of the two packing entry points; `counters` holds 4 (N + 1) int32 (degree counts and
+// fill cursors of the by-destination and by-source lists), zeroed here.
+static int pack_csr_run(const int64_t* edge_index, int64_t E, const int64_t* batch, int64_t N, int32_t B,
+                        int32_t* mol_ptr, int32_t* atom_mol, int32_t* dst_ptr, int32_t* src, int32_t* dst,
+                        int32_t* perm, int32_t* src_ptr, int32_t* src_slot, int32_t* status_dev,
+                        int32_t* counters, hipStream_t s) {
+  int32_t* deg = counters;
   int32_t* sdeg = deg + (N + 1);
   int32_t* cur = sdeg + (N + 1);
   int32_t* cur2 = cur + (N + 1);
@@ -141,6 +137,74 @@ extern "C" int ligdiff_pack_csr(const int64_t* edge_index, int64_t E, const int6
   }
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;
+}
+
+static int pack_csr_check(const int64_t* edge_index, int64_t E, const int64_t* batch, int64_t N, int32_t B,
+                          const int32_t* mol_ptr, const int32_t* atom_mol, const int32_t* dst_ptr, const int32_t* src,
+                          const int32_t* dst, const int32_t* perm, const int32_t* src_ptr, const int32_t* src_slot,
+                          const int32_t* status_dev) {
+  if (N <= 0 || E < 0 || B <= 0 || !batch || !mol_ptr || !atom_mol || !dst_ptr || !src_ptr || !status_dev)
+    return LIGDIFF_ERR_ARG;
+  if (E > 0 && (!edge_index || !src || !dst || !perm || !src_slot)) return LIGDIFF_ERR_ARG;
+  if (N >= (1LL << 30) || E >= (1LL << 30)) return LIGDIFF_ERR_ARG;
+  return LIGDIFF_OK;
+}
+
+extern "C" int ligdiff_pack_csr(const int64_t* edge_index, int64_t E, const int64_t* batch, int64_t N, int32_t B,
+                                int32_t* mol_ptr, int32_t* atom_mol, int32_t* dst_ptr, int32_t* src, int32_t* dst,
+                                int32_t* perm, int32_t* src_ptr, int32_t* src_slot, int32_t* status_dev,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  const int rc = pack_csr_check(edge_index, E, batch, N, B, mol_ptr, atom_mol, dst_ptr, src, dst, perm, src_ptr,
+                                src_slot, status_dev);
+  if (rc) return rc;
+  if (!workspace) return LIGDIFF_ERR_ARG;
+  if (workspace_bytes < ligdiff_pack_workspace_bytes(N, E)) return LIGDIFF_ERR_WORKSPACE;
+  return pack_csr_run(edge_index, E, batch, N, B, mol_ptr, atom_mol, dst_ptr, src, dst, perm, src_ptr, src_slot,
+                      status_dev, (int32_t*)workspace, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ packing without a workspace argument
+// The counters of ligdiff_pack_csr live in a file-scope device array instead of a caller workspace, so
+// the call allocates nothing and needs nothing allocated for it.  Every GPU the library runs on holds
+// its own copy of the array (4.0 MiB) at its own address until the process ends; in host code the
+// array's name is only a handle for hipGetSymbolAddress, whose result (per device) is what the kernels
+// receive.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU race.
+#define PACK_STATIC_MAX_ATOMS LIGDIFF_PACK_STATIC_MAX_ATOMS
+static __device__ __align__(256) int32_t scratch[4 * (PACK_STATIC_MAX_ATOMS + 1)];
+
+#include <mutex>
+#define PACK_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static int32_t* g_scratch_ptr[PACK_MAX_DEVICES];   // device address of `scratch` on each device, once resolved
+
+static int scratch_of_current_device(int32_t** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PACK_MAX_DEVICES) return LIGDIFF_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || p == nullptr) return LIGDIFF_ERR_LAUNCH;
+    g_scratch_ptr[dev] = (int32_t*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return LIGDIFF_OK;
+}
+
+extern "C" int ligdiff_pack_csr_static(const int64_t* edge_index, int64_t E, const int64_t* batch, int64_t N,
+                                       int32_t B, int32_t* mol_ptr, int32_t* atom_mol, int32_t* dst_ptr, int32_t* src,
+                                       int32_t* dst, int32_t* perm, int32_t* src_ptr, int32_t* src_slot,
+                                       int32_t* status_dev, void* stream) {
+  int rc = pack_csr_check(edge_index, E, batch, N, B, mol_ptr, atom_mol, dst_ptr, src, dst, perm, src_ptr, src_slot,
+                          status_dev);
+  if (rc) return rc;
+  if (N > PACK_STATIC_MAX_ATOMS) return LIGDIFF_ERR_WORKSPACE;   // beyond the static array: use ligdiff_pack_csr
+  int32_t* counters = nullptr;
+  rc = scratch_of_current_device(&counters);
+  if (rc) return rc;
+  // pack_csr_run zeroes the 4 (N + 1) counters it uses before counting, so what an earlier call left
+  // behind (also beyond this call's N) never enters a result
+  return pack_csr_run(edge_index, E, batch, N, B, mol_ptr, atom_mol, dst_ptr, src, dst, perm, src_ptr, src_slot,
+                      status_dev, counters, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ template connectivity

@@ -93,6 +93,25 @@ int ligdiff_pack_csr(const int64_t* edge_index, int64_t n_edges, const int64_t* 
                      int32_t* src_ptr, int32_t* src_slot, int32_t* status_dev,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * ligdiff_pack_csr for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): same inputs, outputs, status convention and bit-exact
+ * results, but no workspace argument.  The counters live in a device array that is part of the
+ * library's code object (4 MiB on every GPU the library runs on, held until the process ends), so
+ * the call performs no hipMalloc / hipFree and needs none made for it.  n_atoms above
+ * LIGDIFF_PACK_STATIC_MAX_ATOMS returns LIGDIFF_ERR_WORKSPACE (use ligdiff_pack_csr).  All calls on one
+ * GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race;
+ * calls on different GPUs do not interact.  The first call on a device resolves the array's device
+ * address (hipGetSymbolAddress) and should be made outside stream capture.
+ * No counterpart in the reference (it packs nothing; PyG collate + per-call index arithmetic,
+ * model1.py:88-112, main.py:205-212).
+ */
+#define LIGDIFF_PACK_STATIC_MAX_ATOMS 262144
+int ligdiff_pack_csr_static(const int64_t* edge_index, int64_t n_edges, const int64_t* batch,
+                            int64_t n_atoms, int32_t n_mols, int32_t* mol_ptr, int32_t* atom_mol,
+                            int32_t* dst_ptr, int32_t* src, int32_t* dst, int32_t* perm,
+                            int32_t* src_ptr, int32_t* src_slot, int32_t* status_dev, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Score-network forward.  Replaces ResearchAccurateDiffusionModel.forward in eval mode
  * (model1.py:699-755): embeddings, 3 E(3) message-passing layers (model1.py:86-114),
