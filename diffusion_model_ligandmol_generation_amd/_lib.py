@@ -95,6 +95,7 @@ SIGNATURES = {
     "ligdiff_template_edge_count": (C.c_int64, [C.c_int32]),
     "ligdiff_template_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p]),
+    "ligdiff_full_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "ligdiff_prediction_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ligdiff_validity_gate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
 }

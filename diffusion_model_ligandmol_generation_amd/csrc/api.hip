@@ -31,7 +31,7 @@ extern "C" size_t ligdiff_forward_workspace_bytes(int64_t n_atoms, int64_t n_edg
   return L.total;
 }
 
-static int check_graph(const ligdiff_graph* g) {
+int check_graph(const ligdiff_graph* g) {
   if (!g || g->n_atoms <= 0 || g->n_edges < 0 || g->n_mols <= 0) return LIGDIFF_ERR_ARG;
   if (g->n_atoms >= (1LL << 30) || g->n_edges >= (1LL << 30)) return LIGDIFF_ERR_ARG;
   if (!g->mol_ptr || !g->atom_mol || !g->dst_ptr || !g->src_ptr) return LIGDIFF_ERR_ARG;
@@ -41,18 +41,29 @@ static int check_graph(const ligdiff_graph* g) {
   return LIGDIFF_OK;
 }
 
-extern "C" int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, const float* x,
-                               const float* pos, const float* t, const int32_t* t_index_dev,
-                               const float* properties, int flags, float* atom_pred, float* pos_pred,
-                               float* prop_pred, void* workspace, size_t workspace_bytes, void* stream) {
+// Argument validation shared by ligdiff_forward and ligdiff_forward_timed.
+static int check_forward_args(const float* const* weights, const ligdiff_graph* graph, const float* x, const float* pos,
+                              const float* t, const int32_t* t_index_dev, int flags, const float* atom_pred,
+                              const float* pos_pred, const void* workspace, size_t workspace_bytes) {
   int rc = check_graph(graph);
   if (rc) return rc;
+  if (flags & ~FWD_PUBLIC_FLAGS) return LIGDIFF_ERR_ARG;   // library-internal bits are not part of the ABI
   if (!weights || !x || !pos || (!t && !t_index_dev) || !atom_pred || !pos_pred || !workspace) return LIGDIFF_ERR_ARG;
   for (int i = 0; i < W_COUNT; ++i)
     if (weights[i] == nullptr) return LIGDIFF_ERR_ARG;
   if (t_index_dev && !(flags & LIGDIFF_FWD_T_BROADCAST)) return LIGDIFF_ERR_ARG;
   if (workspace_bytes < ligdiff_forward_workspace_bytes(graph->n_atoms, graph->n_edges, graph->n_mols, flags))
     return LIGDIFF_ERR_WORKSPACE;
+  return LIGDIFF_OK;
+}
+
+extern "C" int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                               const float* pos, const float* t, const int32_t* t_index_dev,
+                               const float* properties, int flags, float* atom_pred, float* pos_pred,
+                               float* prop_pred, void* workspace, size_t workspace_bytes, void* stream) {
+  const int rc = check_forward_args(weights, graph, x, pos, t, t_index_dev, flags, atom_pred, pos_pred, workspace,
+                                    workspace_bytes);
+  if (rc) return rc;
   return run_forward(weights, graph, x, pos, t, t_index_dev, properties, flags, atom_pred, pos_pred, prop_pred,
                      (char*)workspace, (hipStream_t)stream);
 }
@@ -65,13 +76,10 @@ extern "C" int ligdiff_forward_timed(const float* const* weights, const ligdiff_
                                      const float* properties, int flags, float* atom_pred, float* pos_pred,
                                      float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
                                      const char* label, int32_t reps, float* mean_ms_host) {
-  int rc = check_graph(graph);
+  int rc = check_forward_args(weights, graph, x, pos, t, t_index_dev, flags, atom_pred, pos_pred, workspace,
+                              workspace_bytes);
   if (rc) return rc;
-  if (!weights || !x || !pos || (!t && !t_index_dev) || !atom_pred || !pos_pred || !workspace || !label ||
-      reps <= 0 || !mean_ms_host)
-    return LIGDIFF_ERR_ARG;
-  if (workspace_bytes < ligdiff_forward_workspace_bytes(graph->n_atoms, graph->n_edges, graph->n_mols, flags))
-    return LIGDIFF_ERR_WORKSPACE;
+  if (!label || reps <= 0 || !mean_ms_host) return LIGDIFF_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   FwdProbe p;
   p.label = label; p.hits = 0;

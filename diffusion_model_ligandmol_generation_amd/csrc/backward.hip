@@ -176,6 +176,11 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
                                 const float* d_pos, const float* d_prop, const void* fwd_workspace,
                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (!w || !gr || !g || !x || !pos || !d_atom || !d_pos || !fwd_workspace || !workspace) return LIGDIFF_ERR_ARG;
+  {
+    const int grc = check_graph(g);
+    if (grc) return grc;
+  }
+  if (flags & ~FWD_PUBLIC_FLAGS) return LIGDIFF_ERR_ARG;
   if (!(flags & LIGDIFF_FWD_SAVE_FOR_BACKWARD) || (flags & LIGDIFF_FWD_T_BROADCAST)) return LIGDIFF_ERR_ARG;
   // every slot of the score network needs a gradient buffer; the frequency table and the consistency
   // module (slots from W_CONS_0 on: no loss reaches it) have none

@@ -6,6 +6,7 @@
 // P = h [Wi | Wj]^T plus a 4-term sum per pair, so the expensive part costs N rows, not sum n(n-1);
 // the remaining layers are ordinary row GEMMs over the pairs.  Dropout (model1.py:390, :401) is
 // not applied.
+#include "forward.h"
 #include "launch.h"
 #include "weights.h"
 
@@ -210,6 +211,10 @@ extern "C" int ligdiff_consistency(const float* const* w, const ligdiff_graph* g
                                    size_t workspace_bytes, void* stream) {
   if (!w || !g || !h || !pos || !pair_ptr || !atom_logits || !valency || !adjacency || !workspace) return LIGDIFF_ERR_ARG;
   if (n_pairs > 0 && !bond_logits) return LIGDIFF_ERR_ARG;
+  {
+    const int grc = check_graph(g);
+    if (grc) return grc;
+  }
   const int64_t N64 = g->n_atoms;
   if (N64 <= 0 || g->n_mols <= 0 || n_pairs < 0 || n_max < g->max_mol_atoms) return LIGDIFF_ERR_ARG;
   if (N64 > 0x7fffffff / 512 || n_pairs > 0x7fffffff / 256) return LIGDIFF_ERR_ARG;   // int row indices in the GEMMs

@@ -46,6 +46,13 @@ struct FwdProbe { const char* label; hipEvent_t e0, e1; int hits; };
 // conditioning, no saved activations.
 #define FWD_INTERNAL_HALF_COND (1 << 21)
 
+// Bits a caller of the C ABI may set in `flags` (the LIGDIFF_FWD_* values); anything else is refused.
+#define FWD_PUBLIC_FLAGS (LIGDIFF_FWD_PROPERTIES | LIGDIFF_FWD_NULL_COND | LIGDIFF_FWD_SKIP_PROP_HEAD | \
+                          LIGDIFF_FWD_SAVE_FOR_BACKWARD | LIGDIFF_FWD_T_BROADCAST)
+// Shape / pointer validation of a caller's ligdiff_graph, shared by every entry point that takes one
+// (sizes positive and below 2^30, arrays present, largest molecule within LIGDIFF_MAX_ATOMS).
+int check_graph(const ligdiff_graph* g);
+
 // Time embedding + adaLN parameters for n_rows timesteps t[0..n_rows) with the kernels (and the
 // per-row summation order) of the shared-timestep path: temb [n,256], mod_l [n,1536];
 // tf [n,256], t1 [n,512], stemb [n,256] are scratch.

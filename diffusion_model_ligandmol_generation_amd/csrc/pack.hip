@@ -259,3 +259,37 @@ extern "C" int ligdiff_template_edges(const int32_t* mol_ptr, const int64_t* edg
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;
 }
+
+// ------------------------------------------------------------------ fully connected molecules
+// Every ordered pair (i, j != i) of each molecule as a directed edge i -> j, pairs of a molecule in
+// row-major (i, j) order: edge k of a molecule with n atoms has i = k / (n - 1) and j = k % (n - 1),
+// moved past the diagonal.  One thread per edge; the molecule is found by bisection of edge_ptr
+// (exclusive prefix of n (n - 1)).
+__global__ void k_full_edges(const int32_t* __restrict__ mol_ptr, const int64_t* __restrict__ edge_ptr, int32_t B,
+                             int64_t E, int64_t* __restrict__ edge_index) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int lo = 0, hi = B;            // invariant: edge_ptr[lo] <= e < edge_ptr[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (edge_ptr[mid] <= e) lo = mid; else hi = mid;
+  }
+  const int a0 = mol_ptr[lo], n = mol_ptr[lo + 1] - a0;
+  const int k = (int)(e - edge_ptr[lo]);
+  const int i = k / (n - 1);
+  int j = k % (n - 1);
+  j += (j >= i) ? 1 : 0;
+  edge_index[e] = a0 + i;
+  edge_index[E + e] = a0 + j;
+}
+
+extern "C" int ligdiff_full_edges(const int32_t* mol_ptr, const int64_t* edge_ptr, int32_t n_mols, int64_t n_edges,
+                                  int64_t* edge_index, void* stream) {
+  if (!mol_ptr || !edge_ptr || n_mols <= 0 || n_edges < 0) return LIGDIFF_ERR_ARG;
+  if (n_edges == 0) return LIGDIFF_OK;
+  if (!edge_index) return LIGDIFF_ERR_ARG;
+  hipLaunchKernelGGL(k_full_edges, dim3(ceil_div(n_edges, 256)), dim3(256), 0, (hipStream_t)stream, mol_ptr, edge_ptr,
+                     n_mols, n_edges, edge_index);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}

@@ -421,6 +421,10 @@ static int sample_loop(const float* const* weights, const ligdiff_graph* graph, 
                        const int32_t* ddim_ts, int32_t* reject) {
   const bool ddim = ddim_ts != nullptr;
   if (!weights || !graph || !x || !pos || !alphas_cumprod || !workspace || n_steps <= 0) return LIGDIFF_ERR_ARG;
+  {
+    const int grc = check_graph(graph);   // also: no molecule beyond the attention kernel's 128 atoms
+    if (grc) return grc;
+  }
   if (!ddim && (!betas || !alphas)) return LIGDIFF_ERR_ARG;
   if (ddim && !reject) return LIGDIFF_ERR_ARG;
   if (use_graph && stream == nullptr) return LIGDIFF_ERR_ARG;  // the default stream cannot be captured

@@ -139,9 +139,7 @@ class ScoreNetworkEngine:
         N, B = graph.n_atoms, graph.n_mols
         if t is None:
             t = torch.zeros(1, device=self.device)
-        if graph.max_mol_atoms > self.max_atoms:
-            raise RuntimeError(f"a molecule has {graph.max_mol_atoms} atoms but the model was built with "
-                               f"max_atoms={self.max_atoms} (model1.py:728)")
+        self._check_sizes(graph)
         for name, v in (("x", x), ("pos", pos), ("t", t)):
             _require_cuda(v, name)
         x = x.contiguous().float()
@@ -187,6 +185,13 @@ class ScoreNetworkEngine:
         check(rc, "ligdiff_forward")
         self.last_forward = (ws, flags) if keep_state else None   # for consistency() right after this call
         return atom_pred, pos_pred, prop_pred
+
+    def _check_sizes(self, graph):
+        """model1.py:728 pads every molecule to max_atoms: a larger molecule fails there (the reference
+        then returns zeros, model1.py:757-764); here it raises."""
+        if graph.max_mol_atoms > self.max_atoms:
+            raise RuntimeError(f"a molecule has {graph.max_mol_atoms} atoms but the model was built with "
+                               f"max_atoms={self.max_atoms} (model1.py:728)")
 
     def time_launch(self, label, graph, x, pos, t_index, reps=5):
         """Mean duration in ms (HIP events on the launch stream) of one labelled launch of
@@ -270,6 +275,7 @@ class ScoreNetworkEngine:
                     n_steps=None, seed=0, atom_offset=0, use_graph=True):
         """Whole reverse loop in the library (hipGraph replay); x / pos updated in place."""
         n_steps = model.timesteps if n_steps is None else n_steps
+        self._check_sizes(graph)
         guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
         nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
                                                               int(n_steps))
@@ -302,6 +308,7 @@ class ScoreNetworkEngine:
         """Whole DDIM loop in the library (ligdiff_ddim_sample); x / pos updated in place, ``reject``
         [B] int32 receives the per-step prediction gate.  timesteps: list of ints."""
         n_steps = len(timesteps)
+        self._check_sizes(graph)
         guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
         nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
                                                               n_steps)
@@ -347,27 +354,60 @@ class ScoreNetworkEngine:
                                                    _ptr(reject), _stream()), "ligdiff_prediction_gate")
 
 
-def template_graph(sizes, device):
-    """Batch of molecules with the generator's bond template (generation.py:562-668), built
-    on device.  Returns (PackedGraph, edge_index [2,E] int64, kind [E] uint8)."""
-    lib = _lib.load()
-    sizes = [int(n) for n in sizes]
-    if min(sizes) < 1:
-        raise ValueError("molecule sizes must be >= 1")
-    if min(sizes) < 2:
-        raise ValueError("a one-atom molecule has no bonds: outside the generator's supported domain")
+def _size_arrays(sizes, counts, device):
+    """mol_ptr [B+1] int32, edge_ptr [B+1] int64 (exclusive prefixes) on ``device``, batch [N] int64."""
     B = len(sizes)
-    counts = [lib.ligdiff_template_edge_count(n) for n in sizes]
     mol_ptr = torch.zeros(B + 1, dtype=torch.int32)
     mol_ptr[1:] = torch.tensor(sizes, dtype=torch.int64).cumsum(0).to(torch.int32)
     edge_ptr = torch.zeros(B + 1, dtype=torch.int64)
     edge_ptr[1:] = torch.tensor(counts, dtype=torch.int64).cumsum(0)
-    E = int(edge_ptr[-1])
-    mol_ptr_d, edge_ptr_d = mol_ptr.to(device), edge_ptr.to(device)
+    batch = torch.repeat_interleave(torch.arange(B, dtype=torch.int64), torch.tensor(sizes)).to(device)
+    return mol_ptr.to(device), edge_ptr.to(device), int(edge_ptr[-1]), batch
+
+
+def _check_sizes_list(sizes):
+    sizes = [int(n) for n in sizes]
+    if len(sizes) == 0 or min(sizes) < 1:
+        raise ValueError("molecule sizes must be >= 1")
+    if min(sizes) < 2:
+        raise ValueError("a one-atom molecule has no bonds: outside the generator's supported domain")
+    return sizes
+
+
+def template_graph(sizes, device):
+    """Batch of molecules with the generator's bond template (generation.py:562-668), built
+    on device.  Returns (PackedGraph, edge_index [2,E] int64, kind [E] uint8)."""
+    lib = _lib.load()
+    sizes = _check_sizes_list(sizes)
+    B = len(sizes)
+    counts = [lib.ligdiff_template_edge_count(n) for n in sizes]
+    mol_ptr_d, edge_ptr_d, E, batch = _size_arrays(sizes, counts, device)
     edge_index = torch.empty(2, E, dtype=torch.int64, device=device)
     kind = torch.empty(E, dtype=torch.uint8, device=device)
     with torch.cuda.device(device):
         check(lib.ligdiff_template_edges(_ptr(mol_ptr_d), _ptr(edge_ptr_d), B, max(sizes), E, _ptr(edge_index),
                                          _ptr(kind), _stream()), "ligdiff_template_edges")
-    batch = torch.repeat_interleave(torch.arange(B, dtype=torch.int64), torch.tensor(sizes)).to(device)
     return PackedGraph(edge_index, batch, num_mols=B), edge_index, kind
+
+
+def full_graph(sizes, device):
+    """Batch of fully connected molecules: every ordered pair (i, j != i) of a molecule is a directed
+    edge (ligdiff_full_edges), built on device.  Returns (PackedGraph, edge_index [2,E] int64)."""
+    lib = _lib.load()
+    sizes = _check_sizes_list(sizes)
+    B = len(sizes)
+    mol_ptr_d, edge_ptr_d, E, batch = _size_arrays(sizes, [n * (n - 1) for n in sizes], device)
+    edge_index = torch.empty(2, E, dtype=torch.int64, device=device)
+    with torch.cuda.device(device):
+        check(lib.ligdiff_full_edges(_ptr(mol_ptr_d), _ptr(edge_ptr_d), B, E, _ptr(edge_index), _stream()),
+              "ligdiff_full_edges")
+    return PackedGraph(edge_index, batch, num_mols=B), edge_index
+
+
+def graph_from_edges(sizes, edge_index, device):
+    """Batch whose bonds the caller supplies: ``edge_index`` [2,E] int64 holds GLOBAL atom indices
+    (molecule m owns atoms sum(sizes[:m]) .. sum(sizes[:m+1]), as PyG collation numbers them).
+    Returns the PackedGraph."""
+    sizes = _check_sizes_list(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes), dtype=torch.int64), torch.tensor(sizes)).to(device)
+    return PackedGraph(edge_index.to(device), batch, num_mols=len(sizes))

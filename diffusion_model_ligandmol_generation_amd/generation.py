@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .engine import template_graph
+from .engine import PackedGraph, full_graph, graph_from_edges, template_graph
 
 _SINGLE = [1.0, 0.0, 0.0, 0.0, 0.0]
 _AROMATIC = [0.0, 0.0, 0.0, 1.0, 1.0]
@@ -37,7 +37,12 @@ class ResearchValidatedGenerator:
         self.use_ema = use_ema
         self.device = next(model.parameters()).device
         self.batch_atoms = 32768          # atoms per packed sampling batch
-        self.seed = 0
+        self.batch_edges = 4 << 20        # directed edges per packed sampling batch (fully connected molecules)
+        # Philox seed of the next call.  None: every call draws a fresh 62-bit seed from torch's global
+        # CPU generator, so consecutive calls differ (as the reference's torch.randn draws do,
+        # generation.py:291, :405, :469) and torch.manual_seed makes a run repeatable.  An int: used
+        # for the next call and advanced by one per call.
+        self.seed = None
         self.last_stats = {}
         _add_missing_attributes_to_model(self.model)
 
@@ -63,21 +68,41 @@ class ResearchValidatedGenerator:
                            "success_rate": n_ok / max(1, num_molecules)}
         return out
 
+    def _next_seed(self):
+        """Seed for a call that was not given one (see ``self.seed``)."""
+        if self.seed is None:
+            return int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
+        seed = int(self.seed)
+        self.seed = seed + 1
+        return seed
+
+    def _edge_count(self, n, connectivity):
+        if connectivity == "full":
+            return n * (n - 1)
+        return 2 * n + 4
+
     def sample_many(self, sizes, target_properties=None, guidance_scale=2.0, temperature=1.0, use_ddim=False,
-                    num_steps=100, seed=None):
-        """Samples every size in ``sizes``; returns ([(x_np, pos_np)], [accepted bool])."""
-        seed = self.seed if seed is None else seed
+                    num_steps=100, seed=None, connectivity="template"):
+        """Samples every size in ``sizes``; returns ([(x_np, pos_np)], [accepted bool]).
+        connectivity: "template" (the generator's bond template, generation.py:562-668) or "full"
+        (every ordered atom pair of a molecule).  Without ``seed`` every call uses a new one."""
+        seed = self._next_seed() if seed is None else seed
         results, flags = [], []
         i, atom_offset = 0, 0
         with torch.no_grad():
             while i < len(sizes):
-                j, tot = i, 0
-                while j < len(sizes) and (tot + sizes[j] <= self.batch_atoms or j == i):
+                j, tot, etot = i, 0, 0
+                while j < len(sizes):
+                    e_j = self._edge_count(sizes[j], connectivity)
+                    if j > i and (tot + sizes[j] > self.batch_atoms or etot + e_j > self.batch_edges):
+                        break
                     tot += sizes[j]
+                    etot += e_j
                     j += 1
                 chunk = sizes[i:j]
                 x, pos, graph, rejected = self.sample_batch(chunk, target_properties, guidance_scale, temperature,
-                                                            use_ddim, num_steps, seed=seed, atom_offset=atom_offset)
+                                                            use_ddim, num_steps, seed=seed, atom_offset=atom_offset,
+                                                            connectivity=connectivity)
                 accept = self.model.engine().validity_gate(x, pos, graph.mol_ptr, graph.n_mols)
                 accept = (accept.bool() & ~rejected.bool()).cpu().numpy()
                 xh, ph = x.cpu().numpy(), pos.cpu().numpy()       # generation.py:246
@@ -90,8 +115,14 @@ class ResearchValidatedGenerator:
         return results, flags
 
     def sample_batch(self, sizes, target_properties=None, guidance_scale=2.0, temperature=1.0, use_ddim=False,
-                     num_steps=100, seed=0, atom_offset=0, noise=None, use_graph=True, trace=None):
+                     num_steps=100, seed=None, atom_offset=0, noise=None, use_graph=True, trace=None,
+                     connectivity="template"):
         """One packed batch through the reverse loop.  Returns (x, pos, graph, rejected[B]).
+
+        connectivity: "template" (generation.py:409-416, the reference's only choice), "full" (every
+        ordered atom pair of a molecule is an edge), an ``edge_index`` [2,E] int64 tensor of global
+        atom indices in PyG collation numbering, or a ready ``PackedGraph`` for these sizes.
+        seed: Philox key of this call's Gaussian draws; None takes the generator's next seed.
 
         noise: optional callable ``noise(kind, t, shape) -> device tensor`` with kind in
         {"x0", "pos0", "x", "pos"}; when given, every Gaussian draw is taken from it (parity
@@ -99,7 +130,19 @@ class ResearchValidatedGenerator:
         trace: optional callable ``trace(t, x, pos)`` seeing the state that enters step t.
         """
         model, eng, dev = self.model, self.model.engine(), self.device
-        graph, _, _ = template_graph(sizes, dev)
+        seed = self._next_seed() if seed is None else seed
+        if isinstance(connectivity, PackedGraph):
+            graph = connectivity
+            if graph.n_mols != len(sizes) or graph.n_atoms != sum(int(n) for n in sizes):
+                raise ValueError("the packed graph does not describe these molecule sizes")
+        elif torch.is_tensor(connectivity):
+            graph = graph_from_edges(sizes, connectivity, dev)
+        elif connectivity == "full":
+            graph, _ = full_graph(sizes, dev)
+        elif connectivity == "template":
+            graph, _, _ = template_graph(sizes, dev)
+        else:
+            raise ValueError("connectivity must be 'template', 'full', an edge_index tensor or a PackedGraph")
         N, B = graph.n_atoms, graph.n_mols
         props = self._prepare_pilot_properties(target_properties)
         if props is not None:
@@ -160,8 +203,7 @@ class ResearchValidatedGenerator:
         self.model.eval()
         with torch.no_grad():
             x, pos, graph, rejected = self.sample_batch([num_atoms], target_properties, guidance_scale, temperature,
-                                                        use_ddim, num_steps or 0, seed=self.seed)
-            self.seed += 1
+                                                        use_ddim, num_steps or 0)
             if int(rejected[0]) or not self._validate_final_molecule(x, pos, num_atoms):
                 return None
         return x, pos

@@ -110,7 +110,7 @@ class ResearchAccurateDiffusionModel(nn.Module):
         return atom_pred, pos_pred, prop_pred, cons
 
     def sample(self, num_samples=1, target_properties=None, guidance_scale=1.0, num_steps=100, max_atoms=30,
-               seed=0):
+               seed=None):
         """model1.py:890-978 without the RDKit post-processing (model1.py:980-1031, host code that
         is not rebuilt): all ``num_samples`` molecules share each forward.  Returns one dict per
         molecule with what the reference passes on to RDKit: 'positions' [k,3] and 'atom_types' [k]
@@ -118,6 +118,8 @@ class ResearchAccurateDiffusionModel(nn.Module):
         a hydrogen that is not atom 0 into carbon), 'num_atoms' = k; there is no 'smiles' key."""
         from .alt_samplers import ddim_positions
         self.eval()
+        if seed is None:   # a fresh Philox key per call, drawn from torch's global generator (torch.manual_seed repeats it)
+            seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
         pos, atom_pred = ddim_positions(self, num_samples, target_properties, guidance_scale, num_steps, max_atoms,
                                         seed)
         k = min(15, max_atoms)

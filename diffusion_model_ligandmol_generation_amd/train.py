@@ -252,13 +252,15 @@ class ResearchAccurateTrainer:
         torch.save(ckpt, os.path.join("research_checkpoints", "latest_checkpoint.pt"))
 
     def generate_research_validated_molecules(self, num_samples=10, target_properties=None, guidance_scale=7.5,
-                                              num_steps=50, temperature=1.0, top_k=None, seed=0):
+                                              num_steps=50, temperature=1.0, top_k=None, seed=None):
         """train.py:786-892 without the RDKit post-processing (train.py:916-1036, host code with
         random atom typing that is not rebuilt): 25-atom chain + ring graphs, EDM sigma schedule,
         Euler coordinate updates, all molecules in one batch.  Returns one dict per molecule with
         what the reference hands to RDKit: 'positions' [15,3] (train.py:927) and 'num_atoms'."""
         from .alt_samplers import euler_positions
         self.model.eval()
+        if seed is None:   # a fresh Philox key per call, drawn from torch's global generator
+            seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
         pos = euler_positions(self.model, num_samples, target_properties, guidance_scale, num_steps, temperature,
                               25, seed)
         pos = pos.view(num_samples, 25, 3)[:, :15].cpu().numpy()

@@ -2,10 +2,24 @@
  * ligdiff.h - C ABI of the MI355X (gfx950) ligand-diffusion hot path.
  *
  * Plain pointers and sizes only; every pointer named *_dev / every float* / int32_t* /
- * int64_t* argument is a DEVICE pointer unless its comment says "host".  The library
- * keeps no global state and (outside ligdiff_sampler_*, which owns a hipGraph) never
- * allocates: the caller owns all buffers and passes a workspace.  Every entry point
- * takes the hipStream_t (as void*) it enqueues on and returns an int status, 0 = ok.
+ * int64_t* argument is a DEVICE pointer unless its comment says "host".  The caller owns all
+ * buffers and passes a workspace (sizes from the *_workspace_bytes functions); no entry point calls
+ * hipMalloc or hipFree.  Every entry point takes the hipStream_t (as void*) it enqueues on and
+ * returns an int status, 0 = ok.
+ *
+ * Process-wide state, all of it listed here:
+ *  - the GEMM mode (ligdiff_set_split_gemm, or LIGDIFF_GEMM_SPLIT in the environment): it changes what
+ *    the *_workspace_bytes functions return, so size workspaces after choosing it and do not switch
+ *    while another thread is inside a call;
+ *  - LIGDIFF_CFG_TWO_PASS (environment, read at every sampling call and workspace query);
+ *  - A/B switches read once from the environment (LIGDIFF_GEMM_V1, LIGDIFF_GEMM_NOCS, LIGDIFF_ATT_LDS,
+ *    LIGDIFF_ATT_BWD_V1, LIGDIFF_DW_BLOCKS);
+ *  - the per-device scratch array of ligdiff_pack_csr_static.
+ * HIP objects created and destroyed inside a call: ligdiff_ddpm_sample / ligdiff_ddim_sample with
+ * use_graph != 0 capture, instantiate and destroy hipGraphs and synchronise the stream;
+ * ligdiff_forward_timed creates two events and synchronises the stream.  Everything else only
+ * enqueues kernels.  Calls are re-entrant across devices and streams, the exceptions being the two
+ * points above that say otherwise.
  *
  * The reference (Nishanth-nishu/diffusion_model_ligandmol_generation) is pure Python on
  * PyTorch with no FFI of its own; each entry point below names the reference code it
@@ -346,6 +360,15 @@ int64_t ligdiff_template_edge_count(int32_t n_atoms);
 int ligdiff_template_edges(const int32_t* mol_ptr, const int64_t* edge_ptr, int32_t n_mols,
                            int32_t max_mol_atoms, int64_t n_edges, int64_t* edge_index, uint8_t* kind,
                            void* stream);
+
+/* Fully connected molecules (the large-ligand sampling configuration; the reference's sampler only
+ * ever builds the template above, generation.py:409-416, but its model takes any edge_index,
+ * model1.py:723): writes edge_index [2,E] int64 with every ordered pair (i, j != i) of each molecule
+ * as a directed edge i -> j, atom indices offset by the molecule's first atom, pairs in row-major
+ * (i, j) order.  mol_ptr [B+1] int32; edge_ptr [B+1] int64 exclusive prefix of n (n - 1);
+ * n_edges = edge_ptr[B].  Integer, bit-exact. */
+int ligdiff_full_edges(const int32_t* mol_ptr, const int64_t* edge_ptr, int32_t n_mols, int64_t n_edges,
+                       int64_t* edge_index, void* stream);
 
 /* generation.py:518-541 per molecule: reject[m] is SET to 1 (never cleared) when any
  * prediction of molecule m is NaN/Inf or above 100 in magnitude. */

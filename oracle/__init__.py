@@ -12,7 +12,7 @@ diffusion_model_ligandmol_generation_amd/ imports it: the product path is the HI
 library and fails loudly when that library is missing.
 """
 from .schedule import cosine_schedule, edm_scalings, edm_sigma_from_u, edm_loss_weight  # noqa: F401
-from .connectivity import template_connectivity  # noqa: F401
+from .connectivity import template_connectivity, fully_connected_edges  # noqa: F401
 from .packing import pack_csr, collate  # noqa: F401
 from .score_network import score_network_forward, fourier_time_embedding  # noqa: F401
 from .sampler import (ddpm_sample, ddim_sample, validity_gate, ddpm_step, chain_edges,  # noqa: F401

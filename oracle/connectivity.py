@@ -33,3 +33,10 @@ def template_connectivity(n):
     if len(edges) > 8 * n:
         return None
     return edges, feats
+
+
+def fully_connected_edges(n):
+    """Every ordered pair (i, j != i) as the directed edge [i, j], row-major in (i, j): the
+    large-ligand configuration.  The reference's model accepts any edge_index (model1.py:723 passes
+    data.edge_index straight to the E(3) layers); its generator never builds this graph itself."""
+    return [[i, j] for i in range(n) for j in range(n) if j != i]

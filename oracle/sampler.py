@@ -45,7 +45,14 @@ def _predict(sd, x, pos, edge_index, batch, t, props, guidance_scale, max_atoms,
     return a, p
 
 
-def _edges(num_atoms):
+def _edges(num_atoms, edge_index=None):
+    """The generator's bond template (generation.py:409-414), or the caller's [2,E] edge_index of
+    the one molecule (any graph the model accepts, model1.py:723)."""
+    if edge_index is not None:
+        ei = torch.as_tensor(edge_index, dtype=torch.long)
+        if ei.dim() != 2 or ei.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E]")
+        return ei
     conn = template_connectivity(num_atoms)
     if conn is None:
         return None
@@ -57,8 +64,9 @@ def _edges(num_atoms):
 
 def ddpm_sample(sd, sched, num_atoms, noise, target_properties=None, guidance_scale=1.0,
                 temperature=1.0, timesteps=None, max_atoms=100, pad=True, trace=None,
-                atom_feature_dim=119):
-    """generation.py:393-484 up to (not including) the final validity gate.
+                atom_feature_dim=119, edge_index=None):
+    """generation.py:393-484 up to (not including) the final validity gate.  edge_index [2,E]
+    replaces the bond template of generation.py:409-414 when given.
 
     noise(shape) is called in the reference's order: x0, pos0, then per step t > 1 the
     feature noise followed by the coordinate noise.  trace(t, x, pos), if given, sees the
@@ -66,7 +74,7 @@ def ddpm_sample(sd, sched, num_atoms, noise, target_properties=None, guidance_sc
     T = sched["betas"].shape[0] if timesteps is None else timesteps
     x = noise((num_atoms, atom_feature_dim)) * temperature
     pos = noise((num_atoms, 3)) * temperature
-    ei = _edges(num_atoms)
+    ei = _edges(num_atoms, edge_index)
     batch = torch.zeros(num_atoms, dtype=torch.long)
     props = target_properties
     if props is not None and props.dim() == 1:
@@ -89,13 +97,13 @@ def ddim_timesteps(T, num_steps):
 
 def ddim_sample(sd, sched, num_atoms, noise, num_steps, target_properties=None,
                 guidance_scale=1.0, temperature=1.0, max_atoms=100, pad=True, trace=None,
-                atom_feature_dim=119):
-    """generation.py:279-381 up to the final gate.  Returns (x, pos), or None when the
+                atom_feature_dim=119, edge_index=None):
+    """generation.py:279-381 up to the final gate (edge_index as in ddpm_sample).  Returns (x, pos), or None when the
     per-step prediction gate (generation.py:351, :518-541) rejects."""
     T = sched["betas"].shape[0]
     x = noise((num_atoms, atom_feature_dim)) * temperature
     pos = noise((num_atoms, 3)) * temperature
-    ei = _edges(num_atoms)
+    ei = _edges(num_atoms, edge_index)
     batch = torch.zeros(num_atoms, dtype=torch.long)
     ts = ddim_timesteps(T, num_steps)
     props = target_properties

@@ -175,3 +175,29 @@ def test_consistency_module_matches_reference():
     torch.testing.assert_close(a, torch.from_numpy(f["atom_pred"]), rtol=1e-4, atol=1e-5)
     for got, key in zip(cons, ("atom_logits", "bond_logits", "valency", "adjacency")):
         torch.testing.assert_close(got, torch.from_numpy(f[key]), rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_ddpm_sample_takes_caller_edges():
+    """The oracle's whole-loop form with edge_index given equals the step-by-step use above (CPU only,
+    small): guards the checker itself."""
+    T, n = 4, 7
+    sd = seed0_state_dict(timesteps=T, max_atoms=128)
+    sched = oracle.cosine_schedule(T)
+    ei = torch.tensor(oracle.fully_connected_edges(n), dtype=torch.long).t().contiguous()
+    g = torch.Generator().manual_seed(1)
+    draws = []
+
+    def noise(shape):
+        draws.append(torch.randn(*shape, generator=g))
+        return draws[-1]
+
+    with torch.no_grad():
+        x, pos = oracle.ddpm_sample(sd, sched, n, noise, max_atoms=128, pad=False, edge_index=ei)
+        it = iter(draws)
+        x2, p2 = next(it), next(it)
+        for t in range(T - 1, -1, -1):
+            ex, ep, _ = oracle.score_network_forward(sd, x2, p2, ei, torch.zeros(n, dtype=torch.long),
+                                                     torch.tensor([t]), None, max_atoms=128, pad_to_max_atoms=False)
+            zx, zp = (next(it), next(it)) if t > 1 else (None, None)
+            x2, p2 = oracle.ddpm_step(x2, ex, t, sched, zx), oracle.ddpm_step(p2, ep, t, sched, zp)
+    assert torch.equal(x, x2) and torch.equal(pos, p2)
