@@ -6,15 +6,28 @@
 One "step" is one full pass of the hot path over one batch: 1024 synthetic 29-atom ligands
 with the generator's bond template, initial noise, 1000 reverse steps (score-network
 forward + fused posterior update, hipGraph-replayed) and the validity gates, all on
-device, fp32.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
-samples its own 1024 molecules - molecules are independent, so there is no data-path
-collective and scaling is weak; the Philox noise is keyed by the global atom index.
-Prints ONE JSON line on rank 0.
+device, fp32.  With N > 1 every rank (one process per GPU) samples its own 1024 molecules -
+molecules are independent, so there is no data-path collective and scaling is weak; the
+Philox noise is keyed by the global atom index.  Rank 0 prints ONE JSON line.
+
+Launching: under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` each
+process is one rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Started directly as
+``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE, this process touches no GPU: it starts
+the N ranks itself through torch.distributed.run and exits with their status.
+
+Beside the headline the same line carries three bounded legs on the other named workloads
+(``config3_train_step``, ``config4_fc_sampling``, ``config5_ragged_split_sweep``); they run after
+the headline has been measured and can neither change nor (through a watchdog) lose it.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -28,21 +41,67 @@ T_STEPS = 1000
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X dense bf16 matrix peak (2.5 PFLOP/s)
 PEAK_HBM_GBS = 8000.0            # MI355X HBM3E peak
-# HBM-side bytes per launch at this workload from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE,
-# the gfx950 correction for wide reads); the counters cannot be read from inside this process, so
-# these are the figures of the committed profile (profiles/r1_b_pmc_summary.csv), not live ones.
-FFN_UP_TRAFFIC_BYTES = 2 * 43616.9e3 * 1.024 + 118784.0e3 * 1.024
-FFN_UP_SPLIT_TRAFFIC_BYTES = 2 * 49581.6e3 * 1.024 + 118784.0e3 * 1.024   # profiles/r1_e_split_pmc_summary.csv
-AGGREGATE_TRAFFIC_BYTES = 2 * 35435.5e3 * 1.024 + 30404.5e3 * 1.024
+EXTRAS_BUDGET_S = 240.0          # the extra legs are abandoned (headline still printed) beyond this
 
 
-def build_model(device):
+# ------------------------------------------------------------------ launcher
+def spawn_ranks(args, passthrough):
+    """--gpus N > 1 without a torch.distributed environment: start N ranks (one per GPU) before
+    anything here touches a GPU, pass their output through and return their exit status."""
+    rehearse = os.environ.get("LIGDIFF_BENCH_REHEARSE") == "1"
+    have = torch.cuda.device_count()          # counts devices without initialising the runtime
+    if not rehearse and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + passthrough
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------ counters from the committed profile
+def profile_traffic():
+    """HBM-side bytes per launch from the newest committed rocprofv3 PMC summary
+    (profiles/r*_pmc_summary.csv: per-kernel means of FETCH_SIZE and WRITE_SIZE in KB, taken in
+    separate passes).  On gfx950 FETCH_SIZE counts half the bytes of a wide streaming read, so
+    read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.  The counters cannot be read from inside this
+    process; a kernel that the summary does not list gets None."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
+    files = [f for f in files if "split" not in os.path.basename(f)]
+    if not files:
+        return {}, None
+    path = files[-1]
+    vals = {}
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            vals.setdefault(row["Kernel_Name"], {})[row["Counter_Name"]] = float(row["Mean_Counter_Value_KB"])
+    out = {}
+    for name, c in vals.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            out[name] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    return out, os.path.relpath(path, ROOT)
+
+
+def traffic_of(table, *needles):
+    for name, v in table.items():
+        if all(n in name for n in needles):
+            return v
+    return None
+
+
+# ------------------------------------------------------------------ models and CPU baselines
+def build_model(device, max_atoms=100, train=False):
     from diffusion_model_ligandmol_generation_amd import ResearchAccurateDiffusionModel
     torch.manual_seed(0)
-    return ResearchAccurateDiffusionModel().to(device).eval()
+    m = ResearchAccurateDiffusionModel(max_atoms=max_atoms).to(device)
+    return m.train() if train else m.eval()
 
 
-def cpu_baseline(n_steps_cap=None):
+def cpu_baseline():
     """The oracle (CPU restatement, validated against the reference's outputs) running the
     loop the way the reference does: one molecule per forward, padded to max_atoms=100."""
     import oracle
@@ -101,30 +160,229 @@ def mode_name(split):
             if split else "v_mfma_f32_32x32x2_f32 (fp32 matrix pipe)")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------ one rank
+class Ctx:
+    """Rank, device and the fenced timing helper shared by every leg."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # LIGDIFF_BENCH_REHEARSE=1: run the N > 1 code path on a box with ONE GPU (all ranks on cuda:0, gloo
-    # for the barrier and the max-reduce); the numbers of such a run mean nothing.
-    rehearse = os.environ.get("LIGDIFF_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
-    if world > 1:
-        import torch.distributed as dist
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    def __init__(self, args):
+        self.t_start = time.time()
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # LIGDIFF_BENCH_REHEARSE=1: run the N > 1 code path on a box with ONE GPU (all ranks on cuda:0, gloo
+        # for the collectives); the numbers of such a run mean nothing.
+        self.rehearse = os.environ.get("LIGDIFF_BENCH_REHEARSE") == "1"
+        if self.rehearse:
+            self.local_rank = 0
+        self.dist = None
+        if self.world > 1:
+            import datetime
+            import torch.distributed as dist
+            self.dist = dist
+            if self.rehearse:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank),
+                                        timeout=datetime.timedelta(seconds=600))
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.group = self.dist.group.WORLD if self.dist is not None else None
+
+    def fence(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        tt = torch.tensor([seconds], device="cpu" if self.rehearse else self.dev, dtype=torch.float64)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def sum_over_ranks(self, value):
+        if self.dist is None:
+            return value
+        tt = torch.tensor([float(value)], device="cpu" if self.rehearse else self.dev, dtype=torch.float64)
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.SUM)
+        return float(tt.item())
+
+    def timed(self, fn, warmup, steps):
+        """W untimed + K timed calls of fn(i) between barrier + synchronize fences; max over ranks."""
+        for i in range(warmup):
+            fn(10_000 + i)
+        self.fence()
+        t0 = time.time()
+        last = None
+        for i in range(steps):
+            last = fn(i)
+        self.fence()
+        return self.max_over_ranks(time.time() - t0), last
+
+
+def log(ctx, msg):
+    """Progress line on stderr (stdout carries only the JSON line)."""
+    print(f"[bench rank {ctx.rank}/{ctx.world} +{time.time() - ctx.t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def uniform_sizes(n, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, (n,), generator=g).tolist()
+
+
+# ------------------------------------------------------------------ extra legs
+def leg_config3_train_step(ctx, steps=5, warmup=2, mols_per_rank=512):
+    """BASELINE configs[2]: data-parallel training step on drug-like ragged ligands (10-64 atoms, bond
+    templates), 512 molecules per GPU (global batch 4096 on 8 GPUs): EDM noise/loss step, forward
+    with saved activations, backward, ONE flat gradient all-reduce over all ranks, clip, AdamW."""
+    from diffusion_model_ligandmol_generation_amd.engine import template_graph
+    from diffusion_model_ligandmol_generation_amd.train import ResearchAccurateTrainer
+    dev = ctx.dev
+    sizes = uniform_sizes(mols_per_rank, 10, 64, 1234 + ctx.rank)
+    graph, ei, _ = template_graph(sizes, dev)
+    N = graph.n_atoms
+    g = torch.Generator().manual_seed(99 + ctx.rank)
+    types = torch.tensor([1, 6, 7, 8, 9])[torch.multinomial(torch.tensor([.45, .35, .08, .10, .02]), N, True, generator=g)]
+
+    class Batch:
+        pass
+
+    b = Batch()
+    b.x = torch.nn.functional.one_hot(types, 119).float().to(dev)
+    b.pos = (torch.randn(N, 3, generator=g) * 1.5).to(dev)
+    b.edge_index, b.batch = ei, graph.batch
+    model = build_model(dev, 100, train=True)
+    trainer = ResearchAccurateTrainer(model, [], [], [], process_group=ctx.group)
+    dt, _ = ctx.timed(lambda i: trainer.train_step(b), warmup, steps)
+    n_atoms_global = ctx.sum_over_ranks(N)
+    out = {"workload": "configs[2]: ragged 10-64-atom template ligands, 512 molecules per GPU, data-parallel training "
+                       "step (EDM loss, forward, backward, flat gradient all-reduce, clip, AdamW), fp32, train mode",
+           "molecules_per_gpu": mols_per_rank, "global_batch": mols_per_rank * ctx.world,
+           "atoms_global": int(n_atoms_global), "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "molecules_per_s": mols_per_rank * ctx.world * steps / dt,
+           "collective": (("gloo (rehearsal)" if ctx.rehearse else "RCCL all-reduce, 26.4 MB fp32 per step")
+                          if ctx.world > 1 else "none (one rank)")}
+    if ctx.world > 1:      # the gradient all-reduce on its own: one flat fp32 buffer of the gradients' size
+        from diffusion_model_ligandmol_generation_amd.parallel import allreduce_sum_
+        numel = sum(p.grad.numel() for p in model.parameters() if p.grad is not None)
+        flat = torch.zeros(numel, device=dev)
+        dta, _ = ctx.timed(lambda i: allreduce_sum_(flat, ctx.group), 2, 5)
+        out["allreduce"] = {"bytes": numel * 4, "ms": dta / 5 * 1e3,
+                            "bus_GBps": 2.0 * (ctx.world - 1) / ctx.world * numel * 4 / (dta / 5) / 1e9}
+    if ctx.rank == 0:      # dominant backward kernel: the FFN up-projection weight gradient
+        eng = model.engine()
+        u = torch.rand(graph.n_mols, device=dev)
+        ms, (nout, kin, rows) = eng.time_backward_launch(graph, b.x, b.pos, u, wide_dw_index=1, reps=5)
+        flops = 2.0 * nout * kin * rows
+        ach = flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": f"gemm_dw_kernel<4> (dW[{nout},{kin}] += dY^T X over {rows} rows: dit2.ffn_up weight gradient)",
+                           "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms}
+    return out
+
+
+def leg_config4_fc_sampling(ctx, mols_per_rank=48, traffic=None):
+    """BASELINE configs[3]: large ligands (65-128 atoms), every ordered atom pair an edge, 1000-step DDPM;
+    the global molecule list is cut into contiguous ranges balanced by the sum of n^2."""
+    from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
+    from diffusion_model_ligandmol_generation_amd.engine import full_graph
+    from diffusion_model_ligandmol_generation_amd.parallel import shard_ranges
+    dev = ctx.dev
+    sizes = uniform_sizes(mols_per_rank * ctx.world, 65, 128, 4321)
+    lo, hi = shard_ranges(sizes, ctx.world, cost="pairs")[ctx.rank]
+    mine = sizes[lo:hi]
+    model = build_model(dev, 128)
+    gen = ResearchValidatedGenerator(model)
+    eng = model.engine()
+    offset = sum(sizes[:lo])
+
+    def one_pass(i):
+        with torch.no_grad():
+            x, pos, graph, _ = gen.sample_batch(mine, None, 1.0, 1.0, seed=77 + i, atom_offset=offset, connectivity="full")
+            acc = eng.validity_gate(x, pos, graph.mol_ptr, graph.n_mols)
+        return x, pos, graph, acc
+
+    dt, (x, pos, graph, acc) = ctx.timed(one_pass, 0, 1)
+    out = {"workload": "configs[3]: 65-128-atom ligands, fully connected (i != j) edges, 1000-step DDPM, fp32, "
+                       "molecules sharded by sum n^2, no collectives",
+           "molecules": len(sizes), "molecules_rank0": len(mine), "atoms_rank0": graph.n_atoms,
+           "edges_rank0": graph.n_edges, "ddpm_steps": T_STEPS, "seconds": dt,
+           "molecules_per_s": len(sizes) / dt, "ms_per_reverse_step": dt / T_STEPS * 1e3,
+           "finite": bool(torch.isfinite(x).all() and torch.isfinite(pos).all())}
+    if ctx.rank == 0:      # dominant kernel at this shape: the second edge-MLP GEMM ([E,256] x [256,256] + LayerNorm)
+        t_index = torch.full((1,), 500, dtype=torch.int32, device=dev)
+        g2, _ = full_graph(mine, dev)
+        eng.time_launch("e3_1.edge_mlp2", g2, x, pos, t_index, reps=2)
+        ms = eng.time_launch("e3_1.edge_mlp2", g2, x, pos, t_index, reps=5)
+        flops = 2.0 * g2.n_edges * 256 * 256
+        ach = flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": f"gemm_cs_kernel<APtrPlain, EpiLN> (e3_*.edge_mlp2, M={g2.n_edges} K=256 N=256)",
+                           "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms}
+        ms_agg = eng.time_launch("e3_1.aggregate", g2, x, pos, t_index, reps=5)
+        E, N = g2.n_edges, g2.n_atoms
+        bytes_agg = E * 1024.0 + N * 1024.0 + E * 32.0 + N * 36.0
+        out["roofline_aggregation"] = {"kernel": "k_aggregate", "bound": "hbm", "achieved": bytes_agg / (ms_agg * 1e-3) / 1e9,
+                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": bytes_agg / (ms_agg * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                       "avg_launch_ms": ms_agg}
+    return out
+
+
+def leg_config5_ragged_split_sweep(ctx, mols_per_rank=1024):
+    """BASELINE configs[4]: mixed-size ragged ligands (10-128 atoms, bond templates), 1000-step DDPM with
+    the MLP GEMMs on the bf16 matrix pipe (split-operand mode); a bounded slice of the 100k-molecule
+    sweep, packed into batches of at most 32768 atoms, sharded by atoms."""
+    from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
+    from diffusion_model_ligandmol_generation_amd.parallel import shard_ranges
+    dev = ctx.dev
+    sizes = uniform_sizes(mols_per_rank * ctx.world, 10, 128, 555)
+    lo, hi = shard_ranges(sizes, ctx.world, cost="atoms")[ctx.rank]
+    mine = sizes[lo:hi]
+    model = build_model(dev, 128)
+    gen = ResearchValidatedGenerator(model)
+    eng = model.engine()
+    prev = eng.set_split_gemm(True)
+    try:
+        def one_pass(i):
+            res, flags = gen.sample_many(mine, None, 1.0, 1.0, use_ddim=False, seed=31 + i, atom_offset=sum(sizes[:lo]))
+            return res, flags
+        dt, (res, flags) = ctx.timed(one_pass, 0, 1)
+    finally:
+        eng.set_split_gemm(prev)
+    rate = len(sizes) / dt
+    import numpy as np
+    return {"workload": "configs[4]: ragged 10-128-atom template ligands, 1000-step DDPM, MLP GEMMs as split-operand bf16 "
+                        "MFMA (fp32 accumulate), batches of <= 32768 atoms, results copied to the host",
+            "molecules": len(sizes), "atoms": int(sum(sizes)), "ddpm_steps": T_STEPS, "seconds": dt,
+            "molecules_per_s": rate, "extrapolated_100k_sweep_s": 100000.0 / rate,
+            "accepted_rank0": int(sum(flags)),
+            "finite": bool(all(np.isfinite(r[0]).all() and np.isfinite(r[1]).all() for r in res))}
+
+
+def run_extras(ctx, extras, traffic):
+    """Every leg on every rank (their barriers stay matched); a failing leg reports its error."""
+    legs = (("config3_train_step", lambda: leg_config3_train_step(ctx)),
+            ("config4_fc_sampling", lambda: leg_config4_fc_sampling(ctx)),
+            ("config5_ragged_split_sweep", lambda: leg_config5_ragged_split_sweep(ctx)))
+    for name, fn in legs:
+        t0 = time.time()
+        log(ctx, f"leg {name} ...")
+        try:
+            extras[name] = fn()
+            extras[name]["leg_seconds"] = time.time() - t0
+        except Exception as e:   # noqa: BLE001
+            extras[name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+
+
+def run_rank(args):
+    ctx = Ctx(args)
+    world, rank, dev = ctx.world, ctx.rank, ctx.dev
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined", file=sys.stderr)
+        sys.exit(2)
 
     from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
     from diffusion_model_ligandmol_generation_amd.engine import template_graph
@@ -140,37 +398,26 @@ def main():
         with torch.no_grad():
             x, pos, graph, rejected = gen.sample_batch(sizes, None, 1.0, 1.0, seed=2024, atom_offset=offset)
             accept = eng.validity_gate(x, pos, graph.mol_ptr, graph.n_mols)
-        return x, pos, graph, accept
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        return x, pos, int(accept.sum().item())
 
     def timed_run(warmup, steps):
-        """W untimed + K timed passes between barriers; returns (max-over-ranks seconds, accepted, last x, pos)."""
-        for i in range(warmup):
-            one_pass(1000 + i)
-        fence()
-        t0 = time.time()
-        accepted = 0
-        x = pos = None
-        for i in range(steps):
-            x, pos, graph, accept = one_pass(i)
-            accepted += int(accept.sum().item())
-        fence()
-        dt = time.time() - t0
-        if world > 1:
-            tt = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt, accepted, x, pos
+        accepted = [0]
+
+        def fn(i):
+            x, pos, acc = one_pass(i)
+            if i < 10_000:
+                accepted[0] += acc
+            return x, pos
+        dt, (x, pos) = ctx.timed(fn, warmup, steps)
+        return dt, accepted[0], x, pos
 
     # GEMM mode of the library: fp32 matrix pipe unless LIGDIFF_GEMM_SPLIT=1 is in the environment.
     # The headline run uses that mode; the other mode is timed afterwards and reported beside it.
     split_mode = eng.set_split_gemm(False)
     eng.set_split_gemm(split_mode)
+    log(ctx, f"headline: {args.warmup} warm-up + {args.steps} timed passes of {MOLS_PER_GPU} molecules x {T_STEPS} steps ...")
     dt, accepted, x, pos = timed_run(args.warmup, args.steps)
+    log(ctx, f"headline done: {dt:.2f} s; other GEMM mode ...")
     finite = bool(torch.isfinite(x).all() and torch.isfinite(pos).all())
     # (every rank runs it, so the barriers inside stay matched; a failure here must not lose the headline)
     alt_error = None
@@ -182,6 +429,9 @@ def main():
     finally:
         eng.set_split_gemm(split_mode)
 
+    out = None
+    log(ctx, "rooflines / CPU baselines ...")
+    traffic, traffic_src = profile_traffic()
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * MOLS_PER_GPU * args.steps / dt
@@ -189,6 +439,7 @@ def main():
         N = atoms_per_rank
         t_index = torch.full((1,), 500, dtype=torch.int32, device=dev)
         graph, _, _ = template_graph(sizes, dev)
+
         def ffn_up_roofline(split):
             eng.set_split_gemm(split)
             eng.time_launch("dit1.ffn_up", graph, x, pos, t_index, reps=2)           # warm
@@ -199,12 +450,16 @@ def main():
                 ach = flops / (ms * 1e-3) / 1e12
                 return {"kernel": "gemm_cs_kernel<APtrPlain, EpiBiasAct<8,GELU>> (dit*.ffn_up, M=29696 K=256 N=1024)",
                         "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": FFN_UP_TRAFFIC_BYTES, "avg_launch_ms": ms}
+                        "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "traffic": traffic_of(traffic, "gemm_cs_kernel<", "EpiBiasAct<8, 1, false>"),
+                        "traffic_source": traffic_src, "avg_launch_ms": ms}
             # six bf16 x bf16 products per fp32 product: the matrix pipe executes 6x the algorithmic flops
             ach = 6.0 * flops / (ms * 1e-3) / 1e12
             return {"kernel": "gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8,GELU>> (dit*.ffn_up, M=29696 K=256 N=1024)",
                     "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": FFN_UP_SPLIT_TRAFFIC_BYTES, "avg_launch_ms": ms,
+                    "frac": ach / PEAK_BF16_MFMA_TFLOPS,
+                    "traffic": traffic_of(traffic, "gemm_cs_split_kernel<", "EpiBiasAct<8, 1, false>"),
+                    "traffic_source": traffic_src, "avg_launch_ms": ms,
                     "fp32_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
                     "note": "achieved counts the six bf16 MFMA products issued per fp32 product"}
         roofline = ffn_up_roofline(split_mode)
@@ -223,7 +478,8 @@ def main():
         bytes_agg = E * 1024.0 + N * 1024.0 + E * 16.0 * 2 + N * 36.0          # msg rows in, agg rows out, wrel, pos
         agg_gbs = bytes_agg / (ms_agg * 1e-3) / 1e9
         roofline_agg = {"kernel": "k_aggregate (e3_*.aggregate)", "bound": "hbm", "achieved": agg_gbs,
-                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": agg_gbs / PEAK_HBM_GBS, "traffic": AGGREGATE_TRAFFIC_BYTES,
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": agg_gbs / PEAK_HBM_GBS,
+                        "traffic": traffic_of(traffic, "k_aggregate("), "traffic_source": traffic_src,
                         "avg_launch_ms": ms_agg}
         out = {
             "metric": "sampled molecules/sec (1000-step DDPM)", "value": value, "unit": "molecules/s",
@@ -245,10 +501,57 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_batched"] = cpu_baseline_batched()
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+
+    # ---- the other named workloads.  The headline above is final; a watchdog prints it alone if the legs
+    # below do not come back in time (e.g. one rank stuck in a collective), so that it cannot be lost.
+    printed = threading.Lock()
+    extras = {}
+
+    def emit(note=None):
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            line = dict(out)
+            line.update(extras)
+            if note:
+                line["extras_note"] = note
+            print(json.dumps(line), flush=True)
+
+    def watchdog():
+        emit(f"extra legs abandoned after {EXTRAS_BUDGET_S:.0f} s")
+        sys.stdout.flush()
+        os._exit(0)
+
+    if args.no_extras:
+        emit()
+    else:
+        timer = threading.Timer(EXTRAS_BUDGET_S, watchdog)
+        timer.daemon = True
+        timer.start()
+        ctx.fence()
+        run_extras(ctx, extras, traffic)
+        timer.cancel()
+        log(ctx, "extras done")
+        emit()
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    if os.environ.get("LIGDIFF_BENCH_TRACE"):      # debugging aid: Python stacks on stderr every N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["LIGDIFF_BENCH_TRACE"]), repeat=True, file=sys.stderr)
+    run_rank(args)
 
 
 if __name__ == "__main__":

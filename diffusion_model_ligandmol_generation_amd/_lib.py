@@ -62,6 +62,10 @@ SIGNATURES = {
     "ligdiff_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),
+    "ligdiff_backward_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float),
+                                         C.POINTER(C.c_int64)]),
     "ligdiff_edm_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),

@@ -6,12 +6,15 @@ from .engine import PackedGraph
 
 def packed_graph_of(data):
     """Packs ``data`` once and caches the result on the object (a sampler calls the model
-    a thousand times with the same connectivity, generation.py:424)."""
+    a thousand times with the same connectivity, generation.py:424).  The cache key holds the
+    tensors' addresses, shapes and version counters, so an edge_index or batch vector that was
+    replaced OR modified in place is packed again."""
     g = getattr(data, "_ligdiff_graph", None)
     ei, batch = data.edge_index, data.batch
-    if g is None or g.key != (ei.data_ptr(), batch.data_ptr(), tuple(ei.shape), batch.numel()):
+    key = (ei.data_ptr(), batch.data_ptr(), tuple(ei.shape), batch.numel(), ei._version, batch._version)
+    if g is None or getattr(g, "key", None) != key:
         g = PackedGraph(ei, batch)
-        g.key = (ei.data_ptr(), batch.data_ptr(), tuple(ei.shape), batch.numel())
+        g.key = key
         try:
             data._ligdiff_graph = g
         except AttributeError:

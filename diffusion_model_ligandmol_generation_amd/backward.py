@@ -78,6 +78,12 @@ class ScoreNetworkFunction(torch.autograd.Function):
                                       bws.numel(), _stream())
         check(rc, "ligdiff_backward")
         ctx.ws = None
+        # data parallel: the parameter gradients of one backward pass are ONE zero-padded buffer, so the
+        # sum over ranks is one collective on it, with no gather / scatter copies (the views handed to
+        # autograd below then already hold the global gradient)
+        if st.grad_group is not None:
+            from .parallel import allreduce_sum_
+            allreduce_sum_(flat, st.grad_group)
         # parameters that did not take part get no gradient (as autograd would report them):
         # the optimiser then leaves them alone instead of applying weight decay to them
         has_props = bool(ctx.flags & _lib.FWD_PROPERTIES)
@@ -97,6 +103,8 @@ class ScoreNetworkFunction(torch.autograd.Function):
 
     @staticmethod
     def run(model, eng, graph, x, pos, t, properties, null_cond, keep_state=False):
+        """``model.grad_allreduce_group`` (set by a data-parallel trainer, else absent): process group
+        over which backward sums the parameter gradients."""
         N, B = graph.n_atoms, graph.n_mols
         x = x.detach().contiguous().float()
         pos = pos.detach().contiguous().float()
@@ -117,7 +125,8 @@ class ScoreNetworkFunction(torch.autograd.Function):
                     raise ValueError("properties must be [B,15]")
         sd = dict(model.state_dict(keep_vars=True))
         params = [sd[n] for n in eng.names if _has_grad_slot(n)]
-        st = _Ctx(eng=eng, graph=graph, x=x, pos=pos, t=t, props=props, flags=flags, keep_state=keep_state)
+        st = _Ctx(eng=eng, graph=graph, x=x, pos=pos, t=t, props=props, flags=flags, keep_state=keep_state,
+                  grad_group=getattr(model, "grad_allreduce_group", None))
         return ScoreNetworkFunction.apply(st, *params)
 
 
@@ -149,8 +158,8 @@ class EDMLossFunction(torch.autograd.Function):
         with torch.cuda.device(dev):
             check(lib.ligdiff_loss_partial(C.byref(a), _ptr(sums), _stream()), "ligdiff_loss_partial")
             if st.group is not None:                      # data parallel: means over the global batch
-                import torch.distributed as dist
-                dist.all_reduce(sums, group=st.group)
+                from .parallel import allreduce_sum_
+                allreduce_sum_(sums, st.group)
             check(lib.ligdiff_loss_finish(C.byref(a), _ptr(sums), 1.0, _ptr(losses), _ptr(d_atom), _ptr(d_pos),
                                           _ptr(d_prop), _stream()), "ligdiff_loss_finish")
         ctx.save_for_backward(d_atom, d_pos, d_prop)

@@ -57,6 +57,11 @@ __global__ __launch_bounds__(256) void k_transpose_block(const float* __restrict
 // Scratch for the transposed weight block (set per ligdiff_backward call from its workspace).
 static thread_local float* g_wt_scratch = nullptr;
 
+// Measurement hook (ligdiff_backward_timed): the `want`-th launch of the wide weight-gradient kernel
+// gemm_dw_kernel<4> of a backward pass, counted in launch order, is bracketed by two events.
+struct BwdProbe { int want, seen, hits; int64_t nout, kin, rows; hipEvent_t e0, e1; };
+static thread_local BwdProbe* g_bwd_probe = nullptr;
+
 // dW[nout, kin] += dY[rows, nout]^T X[rows, kin] (+ db) for narrow / unaligned shapes (k_dw_direct)
 static void gemm_dw_direct(const float* dY, int lddy, int nout, const float* X, int ldx, int kin, int rows, float* dW,
                            int lddw, hipStream_t s, float* db = nullptr) {
@@ -130,10 +135,18 @@ static bool gemm_dw(const float* dY, int lddy, int nout, const float* X, int ldx
     const int m_split = (int)align_up(ceil_div(rows, splits), 16);
     splits = ceil_div(rows, m_split);
     GemmDwArgs a{dY, lddy, nout, X, ldx, kin, rows, m_split, dW, lddw, db};
-    if (narrow)
+    if (narrow) {
       hipLaunchKernelGGL(gemm_dw_kernel<2>, dim3(bx, by, splits), dim3(512), 0, s, a);
-    else
+    } else {
+      BwdProbe* pr = g_bwd_probe;
+      const bool hit = pr != nullptr && pr->seen++ == pr->want;
+      if (hit) (void)hipEventRecord(pr->e0, s);
       hipLaunchKernelGGL(gemm_dw_kernel<4>, dim3(bx, by, splits), dim3(512), 0, s, a);
+      if (hit) {
+        (void)hipEventRecord(pr->e1, s);
+        pr->hits++; pr->nout = nout; pr->kin = kin; pr->rows = rows;
+      }
+    }
     return db != nullptr;
   }
   OpK a{dY, lddy, nout, rows};
@@ -422,4 +435,51 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
   }
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;
+}
+
+
+// Measurement hook for bench.py: runs `reps` backward passes (gradients keep accumulating into
+// `gr`: give it throw-away buffers) and returns the mean duration, from HIP events on `stream` net of
+// an empty event pair, of the `wide_dw_index`-th gemm_dw_kernel<4> launch of a pass, with its
+// shape in dims3_host = {nout, kin, rows} (dW[nout, kin] += dY[rows, nout]^T X[rows, kin]).
+extern "C" int ligdiff_backward_timed(const float* const* w, float* const* gr, const ligdiff_graph* g, const float* x,
+                                      const float* pos, const float* properties, int flags, const float* d_atom,
+                                      const float* d_pos, const float* d_prop, const void* fwd_workspace,
+                                      void* workspace, size_t workspace_bytes, void* stream, int32_t wide_dw_index,
+                                      int32_t reps, float* mean_ms_host, int64_t* dims3_host) {
+  if (wide_dw_index < 0 || reps <= 0 || !mean_ms_host || !dims3_host) return LIGDIFF_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  BwdProbe p;
+  memset(&p, 0, sizeof p);
+  p.want = wide_dw_index;
+  if (hipEventCreate(&p.e0) != hipSuccess || hipEventCreate(&p.e1) != hipSuccess) return LIGDIFF_ERR_LAUNCH;
+  int rc = LIGDIFF_OK;
+  float empty_ms = 1e30f;
+  for (int i = 0; i < 5; ++i) {
+    float ms = 0.f;
+    if (hipEventRecord(p.e0, s) != hipSuccess || hipEventRecord(p.e1, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess || hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) {
+      rc = LIGDIFF_ERR_LAUNCH;
+      break;
+    }
+    empty_ms = ms < empty_ms ? ms : empty_ms;
+  }
+  double total = 0.0;
+  for (int i = 0; i < reps && rc == LIGDIFF_OK; ++i) {
+    p.seen = 0; p.hits = 0;
+    g_bwd_probe = &p;
+    rc = ligdiff_backward(w, gr, g, x, pos, properties, flags, d_atom, d_pos, d_prop, fwd_workspace, workspace,
+                          workspace_bytes, stream);
+    g_bwd_probe = nullptr;
+    if (rc == LIGDIFF_OK && hipStreamSynchronize(s) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
+    if (rc == LIGDIFF_OK && p.hits != 1) rc = LIGDIFF_ERR_ARG;   // no such launch in this pass
+    float ms = 0.f;
+    if (rc == LIGDIFF_OK && hipEventElapsedTime(&ms, p.e0, p.e1) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
+    total += ms > empty_ms ? ms - empty_ms : 0.f;
+  }
+  (void)hipEventDestroy(p.e0);
+  (void)hipEventDestroy(p.e1);
+  *mean_ms_host = (float)(total / reps);
+  dims3_host[0] = p.nout; dims3_host[1] = p.kin; dims3_host[2] = p.rows;
+  return rc;
 }

@@ -209,6 +209,32 @@ class ScoreNetworkEngine:
         check(rc, f"ligdiff_forward_timed({label})")
         return float(ms.value)
 
+    def time_backward_launch(self, graph, x, pos, t, wide_dw_index, reps=5):
+        """Mean duration in ms of one wide weight-gradient launch of the backward pass in situ
+        (ligdiff_backward_timed) and its shape (nout, kin, rows); measurement hook used by bench.py.
+        Runs a forward with saved activations and ``reps`` backward passes into throw-away gradients."""
+        lib, dev = self.lib, self.device
+        N, B = graph.n_atoms, graph.n_mols
+        flags = _lib.FWD_SAVE_FOR_BACKWARD
+        fws = torch.empty(lib.ligdiff_forward_workspace_bytes(N, graph.n_edges, B, flags), dtype=torch.uint8, device=dev)
+        atom, posp = torch.empty(N, 119, device=dev), torch.empty(N, 3, device=dev)
+        prop = torch.empty(B, 15, device=dev)
+        t = t.reshape(-1).contiguous().float()
+        grads = [torch.zeros(lib.ligdiff_weight_numel(i), device=dev) for i in range(len(self.names))]
+        gtable = (C.c_void_p * len(self.names))(*[g.data_ptr() for g in grads])
+        d_atom, d_pos = torch.randn(N, 119, device=dev) * 1e-3, torch.randn(N, 3, device=dev) * 1e-3
+        bws = torch.empty(lib.ligdiff_backward_workspace_bytes(N, graph.n_edges, B), dtype=torch.uint8, device=dev)
+        ms, dims = C.c_float(0.0), (C.c_int64 * 3)()
+        with torch.cuda.device(dev):
+            check(lib.ligdiff_forward(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(t), None, None, flags,
+                                      _ptr(atom), _ptr(posp), _ptr(prop), _ptr(fws), fws.numel(), _stream()),
+                  "ligdiff_forward(save)")
+            check(lib.ligdiff_backward_timed(self.table, gtable, C.byref(graph.c), _ptr(x), _ptr(pos), None, flags,
+                                             _ptr(d_atom), _ptr(d_pos), None, _ptr(fws), _ptr(bws), bws.numel(),
+                                             _stream(), int(wide_dw_index), int(reps), C.byref(ms), dims),
+                  "ligdiff_backward_timed")
+        return float(ms.value), tuple(int(v) for v in dims)
+
     # ------------------------------------------------------------------ sampler entry points
     def step_args(self, model, x, pos, eps_x, eps_pos, eps_xu=None, eps_pu=None, guidance_scale=1.0,
                   temperature=1.0, t_index=None, noise_x=None, noise_pos=None, seed=0, atom_offset=0):

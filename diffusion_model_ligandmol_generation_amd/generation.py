@@ -82,13 +82,15 @@ class ResearchValidatedGenerator:
         return 2 * n + 4
 
     def sample_many(self, sizes, target_properties=None, guidance_scale=2.0, temperature=1.0, use_ddim=False,
-                    num_steps=100, seed=None, connectivity="template"):
+                    num_steps=100, seed=None, connectivity="template", atom_offset=0):
         """Samples every size in ``sizes``; returns ([(x_np, pos_np)], [accepted bool]).
         connectivity: "template" (the generator's bond template, generation.py:562-668) or "full"
-        (every ordered atom pair of a molecule).  Without ``seed`` every call uses a new one."""
+        (every ordered atom pair of a molecule).  Without ``seed`` every call uses a new one.
+        atom_offset: global index of the first atom (a rank sampling one shard of a larger request
+        passes the atoms that precede its shard, which keeps the draws independent of the sharding)."""
         seed = self._next_seed() if seed is None else seed
         results, flags = [], []
-        i, atom_offset = 0, 0
+        i = 0
         with torch.no_grad():
             while i < len(sizes):
                 j, tot, etot = i, 0, 0

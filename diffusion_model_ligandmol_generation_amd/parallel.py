@@ -36,14 +36,27 @@ def shard_batch(x, pos, edge_index, batch, lo, hi, properties=None):
             None if properties is None else properties[lo:hi])
 
 
+def allreduce_sum_(t, group=None):
+    """In-place sum all-reduce of one tensor.  Backend "nccl" (RCCL over xGMI) reduces the device
+    buffer directly; any other backend (gloo: CPU tests and one-GPU rehearsals) goes through a host
+    copy, which does not depend on that backend's handling of device memory."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl" or not t.is_cuda:
+        dist.all_reduce(t, group=group)
+    else:
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    return t
+
+
 def allreduce_flat(tensors, group=None):
     """Sum-all-reduce a list of tensors as ONE flat buffer (one collective per step: the
     6.6 M fp32 gradients are 26 MB, far below what per-tensor launches would cost)."""
-    import torch.distributed as dist
     if not tensors:
         return
     flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat, group=group)
+    allreduce_sum_(flat, group)
     off = 0
     for t in tensors:
         t.copy_(flat[off:off + t.numel()].view_as(t))

@@ -59,6 +59,9 @@ class ResearchAccurateTrainer:
         if process_group is not None:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+            # the score network's backward sums its parameter gradients over this group (one collective
+            # on the flat gradient buffer it already owns)
+            self.model.grad_allreduce_group = process_group
 
     def _edm_lr_schedule(self, step):
         """train.py:110-117."""
@@ -162,9 +165,11 @@ class ResearchAccurateTrainer:
 
     # ------------------------------------------------------------------ optimisation step
     def _allreduce_gradients(self):
-        """One flat sum all-reduce over every gradient that exists (the same set on every
-        rank: it depends only on whether properties are present)."""
-        if self.group is None:
+        """Gradient sum over the ranks.  Normally already done: the score network's backward reduces
+        its flat gradient buffer in place (``model.grad_allreduce_group``, one collective, no copies).
+        If that hook was removed, fall back to one flat all-reduce over every gradient that exists
+        (the same set on every rank: it depends only on whether properties are present)."""
+        if self.group is None or getattr(self.model, "grad_allreduce_group", None) is not None:
             return
         from .parallel import allreduce_flat
         allreduce_flat([p.grad for p in self.model.parameters() if p.grad is not None], self.group)

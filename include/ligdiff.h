@@ -17,7 +17,7 @@
  *  - the per-device scratch array of ligdiff_pack_csr_static.
  * HIP objects created and destroyed inside a call: ligdiff_ddpm_sample / ligdiff_ddim_sample with
  * use_graph != 0 capture, instantiate and destroy hipGraphs and synchronise the stream;
- * ligdiff_forward_timed creates two events and synchronises the stream.  Everything else only
+ * ligdiff_forward_timed / ligdiff_backward_timed create two events and synchronise the stream.  Everything else only
  * enqueues kernels.  Calls are re-entrant across devices and streams, the exceptions being the two
  * points above that say otherwise.
  *
@@ -171,6 +171,19 @@ int ligdiff_backward(const float* const* weights, float* const* grads, const lig
                      const float* x, const float* pos, const float* properties, int flags,
                      const float* d_atom, const float* d_pos, const float* d_prop,
                      const void* fwd_workspace, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurement hook (no counterpart in the reference): runs `reps` backward passes with the arguments
+ * of ligdiff_backward (gradients keep accumulating into `grads`: pass throw-away buffers) and
+ * returns in *mean_ms_host (host) the mean duration, from HIP events on `stream` net of an empty
+ * event pair, of the wide_dw_index-th launch (in launch order within one pass) of the 256-column
+ * weight-gradient kernel, and in dims3_host (host int64[3]) its shape {nout, kin, rows}:
+ * dW[nout, kin] += dY[rows, nout]^T X[rows, kin], 2 nout kin rows flop.  Creates two events and
+ * synchronises the stream; not for the training path. */
+int ligdiff_backward_timed(const float* const* weights, float* const* grads, const ligdiff_graph* graph,
+                           const float* x, const float* pos, const float* properties, int flags,
+                           const float* d_atom, const float* d_pos, const float* d_prop,
+                           const void* fwd_workspace, void* workspace, size_t workspace_bytes, void* stream,
+                           int32_t wide_dw_index, int32_t reps, float* mean_ms_host, int64_t* dims3_host);
 
 /* ---------------------------------------------------------------------------------
  * EDM noise / loss step.  Replaces ResearchAccurateTrainer._compute_research_exact_loss
