@@ -36,6 +36,9 @@ class ResearchAccurateDiffusionModel(nn.Module):
         if hidden_dim != 256 or num_heads != 8 or atom_feature_dim != 119 or property_dim != 15:
             raise ValueError("the HIP kernels are built for hidden_dim=256, num_heads=8, "
                              "atom_feature_dim=119, property_dim=15")
+        if num_layers != 6:
+            raise ValueError("the HIP library runs three E(3) and three attention layers (num_layers=6, the "
+                             "reference's default, model1.py:580)")
         if max_atoms > 128:
             raise ValueError("max_atoms above 128 is not supported by the attention kernel")
         self.atom_feature_dim = atom_feature_dim
@@ -108,6 +111,90 @@ class ResearchAccurateDiffusionModel(nn.Module):
             with torch.no_grad():
                 cons = eng.consistency(packed_graph_of(data), ws, flags)
         return atom_pred, pos_pred, prop_pred, cons
+
+    def compute_loss(self, data, t, properties=None, loss_weights=None, draws=None):
+        """model1.py:767-888.  Returns (losses, metrics) with the reference's keys.  ``t`` is unused,
+        as in the reference: the model is called with the sampled sigma as its time input and the
+        un-preconditioned noisy coordinates (model1.py:786-805); the coordinate term is
+        mean_atoms(mean_xyz((pos_pred - noise)^2) * w(sigma)) (model1.py:824-826).
+
+        The noising runs in ligdiff_edm_prepare, forward / backward in the HIP library (losses['total']
+        is differentiable w.r.t. the parameters); the scalar reductions are a handful of device
+        tensor ops.  ``draws`` optionally injects the random numbers: 'u' [B] uniforms of the sigma
+        draw, 'noise' [N,3], 'null_rand' [B] uniforms of the null-conditioning mask.
+        The label-gated consistency terms (model1.py:842-886) are evaluated when the batch carries
+        the labels and the model is in train mode; the consistency outputs here carry no gradient."""
+        import ctypes as C
+        import torch.nn.functional as F
+        from ._lib import check
+        from .autograd import packed_graph_of
+        from .engine import _ptr, _stream
+        if loss_weights is None:
+            loss_weights = {"coordinate": 1.0, "atom_type": 0.5, "property": 0.3, "valency": 0.4, "adjacency": 0.6}
+        eng = self.engine()
+        dev = eng.device
+        if not hasattr(data, "batch") or data.batch is None:
+            data.batch = torch.zeros(data.x.shape[0], dtype=torch.long, device=data.x.device)
+        graph = packed_graph_of(data)
+        N, B = graph.n_atoms, graph.n_mols
+        draws = draws or {}
+        edm = self.edm_preconditioning
+        u = draws["u"].to(dev).float() if "u" in draws else torch.rand(B, device=dev)          # model1.py:786
+        pos = data.pos.to(dev).float().contiguous()
+        noise = draws["noise"].to(dev).float().contiguous() if "noise" in draws else torch.randn_like(pos)
+        sigma = edm.sigma_from_u(u)
+        coef = torch.empty(B, 4, device=dev)
+        c_noise = torch.empty(B, device=dev)
+        noisy = torch.empty_like(pos)
+        pre_pos = torch.empty_like(pos)
+        with torch.cuda.device(dev):
+            check(eng.lib.ligdiff_edm_prepare(_ptr(u), _ptr(pos), _ptr(noise), _ptr(graph.atom_mol), N, B,
+                                              float(edm.sigma_min), float(edm.sigma_max), float(edm.sigma_data),
+                                              _ptr(coef), _ptr(c_noise), _ptr(noisy), _ptr(pre_pos), _stream()),
+                  "ligdiff_edm_prepare")
+
+        class _Noisy:
+            pass
+
+        nd = _Noisy()
+        nd.x, nd.pos, nd.edge_index, nd.batch, nd._ligdiff_graph = data.x, noisy, data.edge_index, data.batch, graph
+        atom_pred, pos_pred, prop_pred, cons = self.forward(nd, sigma, properties)
+        zero = lambda: torch.tensor(0.0, device=dev)   # noqa: E731
+        losses = {k: zero() for k in ("total", "coordinate", "atom_type", "property", "valency", "adjacency")}
+        metrics = {"atom_accuracy": 0.0, "valency_mae": 0.0, "adjacency_accuracy": 0.0}
+        batch = graph.atom_mol.long()
+        w = edm.loss_weighting(sigma[batch])
+        coordinate = (((pos_pred - noise) ** 2).mean(dim=-1) * w).mean()
+        losses["coordinate"] = coordinate
+        losses["total"] = losses["total"] + loss_weights["coordinate"] * coordinate
+        if properties is not None and prop_pred is not None:                                   # model1.py:831-839
+            null_rand = draws["null_rand"].to(dev) if "null_rand" in draws else torch.rand(B, device=dev)
+            masked = properties.to(dev).float().clone()
+            masked[null_rand < 0.1] = 0.0
+            property_loss = F.mse_loss(prop_pred, masked)
+            losses["property"] = property_loss
+            losses["total"] = losses["total"] + loss_weights["property"] * property_loss
+        if cons is not None:                                                                   # model1.py:842-886
+            atom_logits, _, valency_pred, adjacency = cons
+            if atom_logits is not None and hasattr(data, "true_atom_types"):
+                al = F.cross_entropy(atom_logits, data.true_atom_types.to(dev))
+                losses["atom_type"] = al
+                losses["total"] = losses["total"] + loss_weights["atom_type"] * al
+                metrics["atom_accuracy"] = (atom_logits.argmax(-1) == data.true_atom_types.to(dev)).float().mean().item()
+            if valency_pred is not None and hasattr(data, "valency_labels"):
+                lab = data.valency_labels.to(dev).float()
+                vl = F.mse_loss(valency_pred, lab)
+                losses["valency"] = vl
+                losses["total"] = losses["total"] + loss_weights["valency"] * vl
+                metrics["valency_mae"] = F.l1_loss(valency_pred, lab).item()
+            if adjacency is not None and hasattr(data, "adjacency_matrix"):
+                pa = adjacency.reshape(-1, 5)
+                ta = data.adjacency_matrix.to(dev).reshape(-1, 5).argmax(-1)
+                adl = F.cross_entropy(pa, ta)
+                losses["adjacency"] = adl
+                losses["total"] = losses["total"] + loss_weights["adjacency"] * adl
+                metrics["adjacency_accuracy"] = (pa.argmax(-1) == ta).float().mean().item()
+        return losses, metrics
 
     def sample(self, num_samples=1, target_properties=None, guidance_scale=1.0, num_steps=100, max_atoms=30,
                seed=None):

@@ -243,17 +243,26 @@ class ResearchAccurateTrainer:
                                            "dit_layers", "equivariant_layers"))
 
     def _save_research_checkpoint(self, epoch, metrics, is_best=False):
-        """train.py:736-784: same dictionary keys and file names (rank 0 only)."""
+        """train.py:736-784: the same dictionary (keys, nested configuration blocks) under the same
+        file names; written by rank 0 only under data parallelism."""
         if self.rank != 0:
             return
         os.makedirs("research_checkpoints", exist_ok=True)
-        ckpt = {"epoch": epoch, "model_state_dict": self.model.state_dict(),
+        m = self.model
+        ckpt = {"epoch": epoch, "step": self.step_count, "model_state_dict": m.state_dict(),
                 "optimizer_state_dict": self.optimizer.state_dict(),
                 "scheduler_state_dict": self.scheduler.state_dict(), "metrics": metrics,
-                "loss_weights": self.loss_weights, "research_compliance": self.research_compliance,
-                "step_count": self.step_count}
-        name = "best_research_model.pt" if is_best else f"checkpoint_epoch_{epoch + 1}.pt"
-        torch.save(ckpt, os.path.join("research_checkpoints", name))
+                "training_metrics": dict(self.training_metrics),
+                "research_compliance": self.research_compliance, "loss_weights": self.loss_weights,
+                "model_config": {"timesteps": getattr(m, "timesteps", 1000), "hidden_dim": getattr(m, "hidden_dim", 256),
+                                 "atom_feature_dim": getattr(m, "atom_feature_dim", 119),
+                                 "max_atoms": getattr(m, "max_atoms", 100)},
+                "research_specs": {"edm_sigma_min": 0.002, "edm_sigma_max": 80.0, "edm_sigma_data": 0.5,
+                                   "pilot_objectives": 8, "moldiff_bond_types": 5, "dit_num_heads": 8,
+                                   "e3_equivariance": True}}
+        if is_best:
+            torch.save(ckpt, os.path.join("research_checkpoints", "best_research_model.pt"))
+        torch.save(ckpt, os.path.join("research_checkpoints", f"checkpoint_epoch_{epoch}.pt"))
         torch.save(ckpt, os.path.join("research_checkpoints", "latest_checkpoint.pt"))
 
     def generate_research_validated_molecules(self, num_samples=10, target_properties=None, guidance_scale=7.5,

@@ -64,3 +64,11 @@ def test_hot_path_has_no_cpu_fallback():
     d.edge_index, d.batch = torch.tensor([[0, 1], [1, 0]]), torch.zeros(2, dtype=torch.long)
     with pytest.raises(RuntimeError):
         seed0_model()(d, torch.zeros(1))
+
+
+def test_constructor_rejects_shapes_the_kernels_are_not_built_for():
+    import pytest
+    from diffusion_model_ligandmol_generation_amd.model import ResearchAccurateDiffusionModel
+    for kw in (dict(num_layers=4), dict(hidden_dim=128), dict(num_heads=4), dict(max_atoms=129)):
+        with pytest.raises(ValueError):
+            ResearchAccurateDiffusionModel(**kw)

@@ -186,3 +186,82 @@ def test_attention_backward_mfma_matches_scalar_kernel_on_large_molecules():
         for k in grads[0]:
             scale = grads[1][k].abs().max().item() + 1e-12
             assert (grads[0][k] - grads[1][k]).abs().max().item() <= 1e-4 * scale, (sizes, k)
+
+
+@pytest.mark.parametrize("tag", ["noprop", "prop", "prop_w"])
+def test_model_compute_loss_matches_reference(tag):
+    """ResearchAccurateDiffusionModel.compute_loss (model1.py:767-888): loss values and the gradients of
+    losses['total'] against the reference's, fed the reference's own random draws."""
+    import copy
+    from conftest import golden, seed0_model
+    f = golden("compute_loss.npz")
+    model = copy.deepcopy(seed0_model()).cuda().eval()
+
+    class Bag:
+        pass
+
+    d = Bag()
+    d.x, d.pos = torch.from_numpy(f["x"]).cuda(), torch.from_numpy(f["pos"]).cuda()
+    d.edge_index, d.batch = torch.from_numpy(f["edge_index"]).cuda(), torch.from_numpy(f["batch"]).cuda()
+    props = None if tag == "noprop" else torch.from_numpy(f["props"]).cuda()
+    weights = None
+    if f"{tag}_weights" in f.files:
+        weights = dict(zip(("coordinate", "atom_type", "property", "valency", "adjacency"), f[f"{tag}_weights"].tolist()))
+    draws = {k: torch.from_numpy(f[f"{tag}_{k}"]) for k in ("u", "noise", "null_rand")}
+    model.zero_grad()
+    losses, metrics = model.compute_loss(d, None, props, weights, draws=draws)
+    assert set(losses) == {"total", "coordinate", "atom_type", "property", "valency", "adjacency"}
+    assert set(metrics) == {"atom_accuracy", "valency_mae", "adjacency_accuracy"}
+    for k, v in losses.items():
+        want = float(f[f"{tag}_loss_{k}"])
+        assert abs(float(v) - want) <= 1e-4 * abs(want) + 1e-7, (k, float(v), want)
+    losses["total"].backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        key = f"{tag}_gradsum_{name}"
+        if key not in f.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        gd = p.grad.double().cpu()
+        want = f[key]
+        scale = float(np.sqrt(want[2])) + 1e-12            # l2 norm of the reference gradient
+        assert abs(float((gd ** 2).sum()) ** 0.5 - scale) <= 1e-3 * scale, name
+        gk = f"{tag}_grad_{name}"
+        if gk in f.files:
+            ref = f[gk]
+            assert float(np.abs(gd.numpy() - ref).max()) <= 1e-4 * float(np.abs(ref).max()) + 1e-9 * scale, name
+            checked += 1
+    assert checked > 20
+
+
+def test_checkpoint_round_trip_has_the_reference_layout(tmp_path, monkeypatch):
+    """train.py:736-784: same dictionary keys and file names; a saved model_state_dict loads into a
+    fresh model (strict) and reproduces the forward pass bit for bit."""
+    monkeypatch.chdir(tmp_path)
+    tr = _trainer()
+    tr.step_count = 7
+    tr.training_metrics["train_total_loss"].append(1.5)
+    tr._save_research_checkpoint(3, {"total_loss": 1.5}, is_best=True)
+    import os
+    names = sorted(os.listdir(tmp_path / "research_checkpoints"))
+    assert names == ["best_research_model.pt", "checkpoint_epoch_3.pt", "latest_checkpoint.pt"]
+    ck = torch.load(tmp_path / "research_checkpoints" / "latest_checkpoint.pt", weights_only=False)
+    assert set(ck) == {"epoch", "step", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "metrics",
+                       "training_metrics", "research_compliance", "loss_weights", "model_config", "research_specs"}
+    assert ck["epoch"] == 3 and ck["step"] == 7 and ck["training_metrics"]["train_total_loss"] == [1.5]
+    assert ck["model_config"] == {"timesteps": 1000, "hidden_dim": 256, "atom_feature_dim": 119, "max_atoms": 100}
+    assert ck["research_specs"]["pilot_objectives"] == 8 and ck["research_specs"]["edm_sigma_max"] == 80.0
+    from diffusion_model_ligandmol_generation_amd import ResearchAccurateDiffusionModel
+    torch.manual_seed(99)
+    fresh = ResearchAccurateDiffusionModel().cuda().eval()
+    fresh.load_state_dict(ck["model_state_dict"], strict=True)
+    f = golden("forward.npz")
+    d = Bag(x=torch.from_numpy(f["x"]).cuda(), pos=torch.from_numpy(f["pos"]).cuda(),
+            edge_index=torch.from_numpy(f["edge_index"]).cuda(), batch=torch.from_numpy(f["batch"]).cuda())
+    t = torch.from_numpy(f["t_int"]).cuda()
+    with torch.no_grad():
+        a1, p1, r1, _ = fresh(d, t)
+        tr.model.eval()
+        a2, p2, r2, _ = tr.model(d, t)
+    assert torch.equal(a1, a2) and torch.equal(p1, p2) and torch.equal(r1, r2)
+    torch.testing.assert_close(a1.cpu(), torch.from_numpy(f["int_noprop_atom"]), rtol=1e-4, atol=2e-5)
