@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256) void k_loss_grad(LossIn a, const float* __rest
       pp[c] = a.pos_pred[o + c];
       den[c] = c_skip * a.noisy[o + c] + c_out * pp[c];
       const float d = den[c] - a.pos[o + c];
-      gd[c] = (W0 * w + W5) * 2.0f * d * inv3n + W1 * 0.1f * 2.0f * (d - a.noise[o + c]) * inv3n + ktr * com[c];
+      // a term left out of the total (weight 0: absent, NaN or Inf) sends NO gradient - selected, not
+      // multiplied, because its own derivative may be NaN / Inf (train.py:430-437)
+      gd[c] = (W0 != 0.f ? W0 * w * 2.0f * d * inv3n : 0.f) + (W5 != 0.f ? W5 * 2.0f * d * inv3n : 0.f) +
+              (W1 != 0.f ? W1 * 0.1f * 2.0f * (d - a.noise[o + c]) * inv3n : 0.f) + (W7 != 0.f ? ktr * com[c] : 0.f);
       pn2 += pp[c] * pp[c];
     }
     if (rot) {
@@ -238,9 +241,9 @@ __global__ __launch_bounds__(256) void k_loss_grad(LossIn a, const float* __rest
       }
     }
     const float nr = sqrtf(pn2);
-    const float kn = nr > 0.f ? W4 * 0.01f * 2.0f * (nr - 1.0f) / n_atoms_g / nr : 0.f;
+    const float kn = (nr > 0.f && W4 != 0.f) ? W4 * 0.01f * 2.0f * (nr - 1.0f) / n_atoms_g / nr : 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) g.d_pos[o + c] = gd[c] * c_out + kn * pp[c];
+    for (int c = 0; c < 3; ++c) g.d_pos[o + c] = gd[c] * c_out + (W4 != 0.f ? kn * pp[c] : 0.f);
   }
   const float ka = W3 * 0.1f * 2.0f / ((float)(LD_A - 1) * n_atoms_g);
   for (int i = 0; i < n; ++i) {
@@ -249,12 +252,12 @@ __global__ __launch_bounds__(256) void k_loss_grad(LossIn a, const float* __rest
     const float v1 = lane + 64 < LD_A ? row[lane + 64] : 0.f;
     const float mean = wave_sum(v0 + v1) * (1.0f / LD_A);
     float* orow = g.d_atom + (size_t)(a0 + i) * LD_A;
-    if (lane < LD_A) orow[lane] = ka * (v0 - mean);
-    if (lane + 64 < LD_A) orow[lane + 64] = ka * (v1 - mean);
+    if (lane < LD_A) orow[lane] = W3 != 0.f ? ka * (v0 - mean) : 0.f;
+    if (lane + 64 < LD_A) orow[lane + 64] = W3 != 0.f ? ka * (v1 - mean) : 0.f;
   }
   if (g.d_prop != nullptr && lane < LD_P) {
     float v = 0.f;
-    if (a.props != nullptr)
+    if (a.props != nullptr && W2 != 0.f)
       v = W2 * 0.2f * 2.0f * (a.prop_pred[(size_t)mol * LD_P + lane] - a.props[(size_t)mol * LD_P + lane]) /
           ((float)LD_P * n_mols_g);
     g.d_prop[(size_t)mol * LD_P + lane] = v;

@@ -17,5 +17,5 @@ from .packing import pack_csr, collate  # noqa: F401
 from .score_network import score_network_forward, fourier_time_embedding  # noqa: F401
 from .sampler import (ddpm_sample, ddim_sample, validity_gate, ddpm_step, chain_edges,  # noqa: F401
                       model_sample_positions, trainer_euler_positions, edm_sigma_steps)
-from .loss_step import loss_step  # noqa: F401
+from .loss_step import loss_step, loss_terms  # noqa: F401
 from .consistency import consistency_forward  # noqa: F401,E402

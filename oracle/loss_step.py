@@ -53,6 +53,17 @@ def loss_step(sd, x, pos, edge_index, batch, u, noise, properties=None, null_ran
             props[null_rand < 0.1] = 0.0
     atom_pred, pos_pred, prop_pred = score_network_forward(
         sd, x, pre, edge_index, batch, c_noise, props, max_atoms=max_atoms, pad_to_max_atoms=False)
+    L, den = loss_terms(atom_pred, pos_pred, prop_pred, pos, noise, noisy, c_skip, c_out, w, batch, props)
+    aux = {"sigma": sigma, "denoised_pos": den, "atom_pred": atom_pred, "pos_pred": pos_pred,
+           "prop_pred": prop_pred}
+    return L, aux
+
+
+def loss_terms(atom_pred, pos_pred, prop_pred, pos, noise, noisy, c_skip, c_out, w, batch, props):
+    """Everything of train.py:358-437 that follows the model call: denoised coordinates, the loss
+    families (train.py:454-473, :475-498, :603-623, :625-663), the weighted total with its NaN / Inf
+    skip rule (train.py:430-437) and the family totals.  Returns (losses dict, denoised_pos)."""
+    B = int(batch.max().item()) + 1
     den = c_skip[batch].unsqueeze(-1) * noisy + c_out[batch].unsqueeze(-1) * pos_pred  # :360-362
     L = {}
     L["edm_coordinate"] = (F.mse_loss(den, pos, reduction="none") * w[batch].unsqueeze(-1)).mean()
@@ -83,9 +94,7 @@ def loss_step(sd, x, pos, edge_index, batch, u, noise, properties=None, null_ran
     L["dit_total"] = L["dit_attention"] + L["dit_adaptive_norm"]
     L["e3_total"] = sum((L[k] for k in ("e3_coordinate", "e3_rotation", "e3_translation") if k in L), torch.tensor(0.0))
     L["total_loss"] = total
-    aux = {"sigma": sigma, "denoised_pos": den, "atom_pred": atom_pred, "pos_pred": pos_pred,
-           "prop_pred": prop_pred}
-    return L, aux
+    return L, den
 
 
 def _loss_step_shard(sd, x, pos, edge_index, batch, u, noise, properties, null_rand, training, max_atoms,
