@@ -33,6 +33,12 @@ class StepArgs(C.Structure):
                 ("seed", C.c_uint64), ("atom_offset", C.c_int64), ("n_atoms", C.c_int64)]
 
 
+class Dropout(C.Structure):
+    """struct ligdiff_dropout"""
+    _fields_ = [("seed", C.c_uint64), ("atom_offset", C.c_int64), ("p_attention", C.c_float * 3),
+                ("p_ffn_hidden", C.c_float * 3), ("p_ffn_out", C.c_float * 3)]
+
+
 class LossArgs(C.Structure):
     """struct ligdiff_loss_args"""
     _fields_ = [("pos", C.c_void_p), ("noise", C.c_void_p), ("noisy", C.c_void_p), ("coef", C.c_void_p),
@@ -58,6 +64,13 @@ SIGNATURES = {
     "ligdiff_forward": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
+    "ligdiff_forward_train": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.POINTER(Dropout)]),
+    "ligdiff_backward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p, C.POINTER(Dropout)]),
+    "ligdiff_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "ligdiff_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "ligdiff_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

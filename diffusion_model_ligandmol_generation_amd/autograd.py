@@ -28,10 +28,11 @@ def score_network_apply(model, data, t, properties=None, classifier_free_guidanc
         data.batch = batch
     graph = packed_graph_of(data)
     eng = model.engine()
+    dropout = model.dropout_spec(getattr(data, "atom_offset", 0), getattr(data, "dropout_seed", None))
     needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     if needs_grad:
         from .backward import ScoreNetworkFunction
         return ScoreNetworkFunction.run(model, eng, graph, data.x, data.pos, t, properties, classifier_free_guidance,
-                                        keep_state)
+                                        keep_state, dropout)
     return eng.forward(graph, data.x, data.pos, t, properties, null_cond=classifier_free_guidance,
-                       keep_state=keep_state)
+                       keep_state=keep_state, dropout=dropout)

@@ -35,10 +35,10 @@ class ScoreNetworkFunction(torch.autograd.Function):
         posp = torch.empty(N, 3, dtype=torch.float32, device=eng.device)
         prop = torch.empty(B, 15, dtype=torch.float32, device=eng.device)
         with torch.cuda.device(eng.device):
-            rc = lib.ligdiff_forward(eng.table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.t), None,
-                                     _ptr(st.props), flags, _ptr(atom), _ptr(posp), _ptr(prop), _ptr(ws), ws.numel(),
-                                     _stream())
-        check(rc, "ligdiff_forward(save)")
+            rc = lib.ligdiff_forward_train(eng.table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.t), None,
+                                           _ptr(st.props), flags, _ptr(atom), _ptr(posp), _ptr(prop), _ptr(ws),
+                                           ws.numel(), _stream(), C.byref(st.dropout) if st.dropout is not None else None)
+        check(rc, "ligdiff_forward_train(save)")
         ctx.st, ctx.ws, ctx.flags = st, ws, flags
         st.eng.last_forward = (ws, flags) if st.keep_state else None   # for consistency() right after this call
         ctx.param_shapes = [p.shape for p in params]
@@ -73,10 +73,11 @@ class ScoreNetworkFunction(torch.autograd.Function):
         nbytes = lib.ligdiff_backward_workspace_bytes(N, graph.n_edges, B)
         bws = eng.workspace(nbytes)
         with torch.cuda.device(dev):
-            rc = lib.ligdiff_backward(eng.table, table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.props),
-                                      ctx.flags, _ptr(d_atom), _ptr(d_pos), _ptr(d_prop), _ptr(ctx.ws), _ptr(bws),
-                                      bws.numel(), _stream())
-        check(rc, "ligdiff_backward")
+            rc = lib.ligdiff_backward_train(eng.table, table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.props),
+                                            ctx.flags, _ptr(d_atom), _ptr(d_pos), _ptr(d_prop), _ptr(ctx.ws), _ptr(bws),
+                                            bws.numel(), _stream(),
+                                            C.byref(st.dropout) if st.dropout is not None else None)
+        check(rc, "ligdiff_backward_train")
         ctx.ws = None
         # data parallel: the parameter gradients of one backward pass are ONE zero-padded buffer, so the
         # sum over ranks is one collective on it, with no gather / scatter copies (the views handed to
@@ -102,7 +103,7 @@ class ScoreNetworkFunction(torch.autograd.Function):
         return (None, *out)
 
     @staticmethod
-    def run(model, eng, graph, x, pos, t, properties, null_cond, keep_state=False):
+    def run(model, eng, graph, x, pos, t, properties, null_cond, keep_state=False, dropout=None):
         """``model.grad_allreduce_group`` (set by a data-parallel trainer, else absent): process group
         over which backward sums the parameter gradients."""
         N, B = graph.n_atoms, graph.n_mols
@@ -125,7 +126,7 @@ class ScoreNetworkFunction(torch.autograd.Function):
                     raise ValueError("properties must be [B,15]")
         sd = dict(model.state_dict(keep_vars=True))
         params = [sd[n] for n in eng.names if _has_grad_slot(n)]
-        st = _Ctx(eng=eng, graph=graph, x=x, pos=pos, t=t, props=props, flags=flags, keep_state=keep_state,
+        st = _Ctx(eng=eng, graph=graph, x=x, pos=pos, t=t, props=props, flags=flags, keep_state=keep_state, dropout=dropout,
                   grad_group=getattr(model, "grad_allreduce_group", None))
         return ScoreNetworkFunction.apply(st, *params)
 

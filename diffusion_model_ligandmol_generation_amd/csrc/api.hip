@@ -57,15 +57,26 @@ static int check_forward_args(const float* const* weights, const ligdiff_graph* 
   return LIGDIFF_OK;
 }
 
+extern "C" int ligdiff_forward_train(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                                     const float* pos, const float* t, const int32_t* t_index_dev,
+                                     const float* properties, int flags, float* atom_pred, float* pos_pred,
+                                     float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
+                                     const ligdiff_dropout* dropout) {
+  int rc = check_forward_args(weights, graph, x, pos, t, t_index_dev, flags, atom_pred, pos_pred, workspace,
+                              workspace_bytes);
+  if (rc) return rc;
+  rc = check_dropout(dropout);
+  if (rc) return rc;
+  return run_forward(weights, graph, x, pos, t, t_index_dev, properties, flags, atom_pred, pos_pred, prop_pred,
+                     (char*)workspace, (hipStream_t)stream, nullptr, nullptr, dropout);
+}
+
 extern "C" int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, const float* x,
                                const float* pos, const float* t, const int32_t* t_index_dev,
                                const float* properties, int flags, float* atom_pred, float* pos_pred,
                                float* prop_pred, void* workspace, size_t workspace_bytes, void* stream) {
-  const int rc = check_forward_args(weights, graph, x, pos, t, t_index_dev, flags, atom_pred, pos_pred, workspace,
-                                    workspace_bytes);
-  if (rc) return rc;
-  return run_forward(weights, graph, x, pos, t, t_index_dev, properties, flags, atom_pred, pos_pred, prop_pred,
-                     (char*)workspace, (hipStream_t)stream);
+  return ligdiff_forward_train(weights, graph, x, pos, t, t_index_dev, properties, flags, atom_pred, pos_pred, prop_pred,
+                               workspace, workspace_bytes, stream, nullptr);
 }
 
 // Measurement hook for bench.py: runs `reps` forwards on `stream` and returns the mean

@@ -79,10 +79,14 @@ static void gemm_dw_direct(const float* dY, int lddy, int nout, const float* X, 
 // When the shape allows (ncols a multiple of 256, K of 16, aligned rows) the weight block is
 // transposed into scratch - a few hundred KB - and the product runs on the forward pass's LDS-DMA
 // kernel, whose operands both need the reduction index contiguous.
+// drop (column-split path only, the caller checks): dropout site whose mask multiplies the result.
 template <int NT, int MUL, bool ACCUM>
 static void gemm_dx(const float* dY, int lddy, int M, int K, const float* W, int ldw, int ncols, float* C, int ldc,
-                    const float* pre, int ldp, hipStream_t s) {
+                    const float* pre, int ldp, hipStream_t s, const DropSite* drop = nullptr) {
   if (M <= 0) return;
+  DropSite ds;
+  memset(&ds, 0, sizeof ds);
+  if (drop != nullptr) ds = *drop;
   if (NT == 8 && use_cs() && g_wt_scratch != nullptr && ncols % 256 == 0 && K % G2_BK == 0 && lddy % 4 == 0 &&
       ncols / 256 <= 8 && (size_t)K * ncols <= 1536 * 256) {
     if (split_gemm_enabled()) {   // split-operand mode: W^T goes straight into the split-bf16 block layout
@@ -94,7 +98,7 @@ static void gemm_dx(const float* dY, int lddy, int M, int K, const float* W, int
       SplitW sw;
       memset(&sw, 0, sizeof sw);
       for (int b = 0; b < ncols / 256; ++b) sw.blk[b] = ws + (size_t)b * (K / 16) * G4_CHUNK_ELEMS(4);
-      EpiBwdStore<8, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f};
+      EpiBwdStore<8, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f, ds};
       hipLaunchKernelGGL((gemm_cs_split_kernel<APtrPlain, EpiBwdStore<8, MUL, ACCUM>, 4>), dim3(ceil_div(M, 128), ncols / 256),
                          dim3(512), 0, s, g, sw, APtrPlain{dY, lddy}, e);
       return;
@@ -102,13 +106,13 @@ static void gemm_dx(const float* dY, int lddy, int M, int K, const float* W, int
     hipLaunchKernelGGL(k_transpose_block, dim3(ceil_div(ncols, 32), ceil_div(K, 32)), dim3(256), 0, s, W, K, ncols, ldw,
                        g_wt_scratch);
     GemmCore g = core_blocks(M, K, 256, g_wt_scratch, K, ncols / 256, 256);
-    EpiBwdStore<8, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f};
+    EpiBwdStore<8, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f, ds};
     launch_gemm_cs(g, APtrPlain{dY, lddy}, e, ncols / 256, s);
     return;
   }
   OpRow a{dY, lddy, M, K};
   OpK b{W, ldw, ncols, K};
-  EpiBwdStore<NT, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f};
+  EpiBwdStore<NT, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f, ds};   // (this path ignores ds: see check_dropout)
   dim3 grid(ceil_div(M, G_BM), ceil_div(ncols, NT * 32), 1);
   hipLaunchKernelGGL((gemm_bwd_kernel<NT, OpRow, OpK, EpiBwdStore<NT, MUL, ACCUM>>), grid, dim3(256), 0, s, a, b,
                      (int)align_up(K, 32), e);
@@ -184,11 +188,16 @@ __global__ void k_gelu_elem(const float* __restrict__ in, float* __restrict__ ou
   if (i < n) out[i] = gelu_exact(in[i]);
 }
 
-extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const ligdiff_graph* g, const float* x,
-                                const float* pos, const float* properties, int flags, const float* d_atom,
-                                const float* d_pos, const float* d_prop, const void* fwd_workspace,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, const ligdiff_graph* g, const float* x,
+                                      const float* pos, const float* properties, int flags, const float* d_atom,
+                                      const float* d_pos, const float* d_prop, const void* fwd_workspace,
+                                      void* workspace, size_t workspace_bytes, void* stream,
+                                      const ligdiff_dropout* dropout) {
   if (!w || !gr || !g || !x || !pos || !d_atom || !d_pos || !fwd_workspace || !workspace) return LIGDIFF_ERR_ARG;
+  {
+    const int drc = check_dropout(dropout);
+    if (drc) return drc;
+  }
   {
     const int grc = check_graph(g);
     if (grc) return grc;
@@ -254,25 +263,48 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
     float* dmod = T(L.dmod[l]);
     float* t256b = T(L.n256b);
     float* t256c = T(L.n256c);
-    // x2 = x1 + gate_mlp * (ffh W3^T + b)
-    hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dxa, A(F.fproj[l]), mod, 1536, 1280, g->mol_ptr, B, t256b, dmod);
+    DropSite d_att, d_hid, d_out;
+    if (!make_drop_site(dropout, l, LIGDIFF_DROP_ATTENTION, &d_att) || !make_drop_site(dropout, l, LIGDIFF_DROP_FFN_HIDDEN, &d_hid) ||
+        !make_drop_site(dropout, l, LIGDIFF_DROP_FFN_OUT, &d_out))
+      return LIGDIFF_ERR_ARG;
+    // x2 = x1 + gate_mlp * Dropout(ffh W3^T + b)   (fproj holds the masked projection)
+    hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dxa, A(F.fproj[l]), mod, 1536, 1280, g->mol_ptr, B, t256b, dmod,
+                       d_out);
     if (!gemm_dw<8>(t256b, 256, 256, A(F.ffh[l]), 1024, 1024, N, gr[W_DIT(l, DIT_FF3_W)], 1024, s, gr[W_DIT(l, DIT_FF3_B)]))
       colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_FF3_B)], s);
     float* dffh = T(L.n1024);
     gemm_dx<8, MUL_GELU_GRAD, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1024, dffh, 1024,
-                                     A(F.ffh_pre[l]), 1024, s);
+                                     A(F.ffh_pre[l]), 1024, s, &d_hid);   // ffh = Dropout(GELU(pre))
     if (!gemm_dw<8>(dffh, 1024, 1024, A(F.xn2[l]), 256, 256, N, gr[W_DIT(l, DIT_FF0_W)], 256, s, gr[W_DIT(l, DIT_FF0_B)]))
       colsum(dffh, 1024, N, 1024, nullptr, gr[W_DIT(l, DIT_FF0_B)], s);
     gemm_dx<8, MUL_NONE, false>(dffh, 1024, N, 1024, w[W_DIT(l, DIT_FF0_W)], 256, 256, t256c, 256, nullptr, 0, s);
     hipLaunchKernelGGL(k_lnmod_bwd, dim3(B), dim3(256), 0, s, A(F.x1[l]), t256c, dxa, mod, 1536, 768, 1024,
                        g->mol_ptr, B, dxa, dmod);
     // x1 = x_in + gate_msa * (att Wo^T + b)
-    hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dxa, A(F.oproj[l]), mod, 1536, 512, g->mol_ptr, B, t256b, dmod);
+    hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dxa, A(F.oproj[l]), mod, 1536, 512, g->mol_ptr, B, t256b, dmod,
+                       DropSite{});
     if (!gemm_dw<8>(t256b, 256, 256, A(F.att[l]), 256, 256, N, gr[W_DIT(l, DIT_OUT_W)], 256, s, gr[W_DIT(l, DIT_OUT_B)]))
       colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_OUT_B)], s);
     gemm_dx<8, MUL_NONE, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_OUT_W)], 256, 256, t256c, 256, nullptr, 0, s);
     float* dqkv = T(L.n768);
-    if (getenv("LIGDIFF_ATT_BWD_V1") != nullptr) {   // scalar reference kernel (A/B switch used by the tests)
+    if (d_att.thr != 0u) {   // probabilities were dropout-masked in the forward pass
+      const int tk = (g->max_mol_atoms + 31) / 32;
+      const float* qkv_l = A(F.qkv[l]);
+      const float* att_l = A(F.att[l]);
+      const float* lse_l = A(F.lse[l]);
+      if (tk == 1)
+        hipLaunchKernelGGL((k_attention_bwd_mfma<1, 4, true>), dim3(ceil_div((long)B * 8, 4)), dim3(256), 4 * 32 * 134 * 4, s,
+                           qkv_l, att_l, t256c, lse_l, g->mol_ptr, dqkv, B, d_att);
+      else if (tk == 2)
+        hipLaunchKernelGGL((k_attention_bwd_mfma<2, 4, true>), dim3(ceil_div((long)B * 8, 4)), dim3(256), 4 * 64 * 134 * 4, s,
+                           qkv_l, att_l, t256c, lse_l, g->mol_ptr, dqkv, B, d_att);
+      else if (tk == 3)
+        hipLaunchKernelGGL((k_attention_bwd_mfma<3, 2, true>), dim3(ceil_div((long)B * 8, 2)), dim3(128), 2 * 96 * 134 * 4, s,
+                           qkv_l, att_l, t256c, lse_l, g->mol_ptr, dqkv, B, d_att);
+      else
+        hipLaunchKernelGGL((k_attention_bwd_mfma<4, 2, true>), dim3(ceil_div((long)B * 8, 2)), dim3(128), 2 * 128 * 134 * 4, s,
+                           qkv_l, att_l, t256c, lse_l, g->mol_ptr, dqkv, B, d_att);
+    } else if (getenv("LIGDIFF_ATT_BWD_V1") != nullptr) {   // scalar reference kernel (A/B switch used by the tests)
       if (g->max_mol_atoms <= 64)
         hipLaunchKernelGGL(k_attention_bwd, dim3(B * 2), dim3(256), att_lds_hpb4, s, A(F.qkv[l]), A(F.att[l]), t256c,
                            A(F.lse[l]), g->mol_ptr, dqkv, 64);
@@ -437,6 +469,14 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
   return LIGDIFF_OK;
 }
 
+
+extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const ligdiff_graph* g, const float* x,
+                                const float* pos, const float* properties, int flags, const float* d_atom,
+                                const float* d_pos, const float* d_prop, const void* fwd_workspace,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  return ligdiff_backward_train(w, gr, g, x, pos, properties, flags, d_atom, d_pos, d_prop, fwd_workspace, workspace,
+                                workspace_bytes, stream, nullptr);
+}
 
 // Measurement hook for bench.py: runs `reps` backward passes (gradients keep accumulating into
 // `gr`: give it throw-away buffers) and returns the mean duration, from HIP events on `stream` net of

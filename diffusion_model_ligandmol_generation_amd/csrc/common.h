@@ -103,5 +103,53 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ------------------------------------------------------------------ Philox4x32-10 and dropout masks
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+// One dropout site of a training forward / backward pass (model1.py:263-274: attention probabilities,
+// FFN hidden after GELU, FFN output).  An element is KEPT iff its 32 random bits are >= thr
+// (thr = p 2^32, so thr == 0 means no dropout) and then scaled by inv_keep = 1 / (1 - p), as
+// torch.nn.functional.dropout does.  The bits of an element are a pure function of (seed, site,
+// global element index): forward and backward regenerate the same mask, and it does not depend on
+// how the batch is cut into shards (row_offset = global index of the call's first atom).
+struct DropSite {
+  uint64_t seed;
+  int64_t row_offset;
+  uint32_t site;
+  uint32_t thr;
+  float inv_keep;
+};
+#define LD_DROP_STREAM 0xD20F0000u
+// Scales of the four elements of quad `quad` of a site.
+__device__ __forceinline__ f32x4 drop_scale4(const DropSite& d, uint64_t quad) {
+  uint32_t c[4] = {(uint32_t)quad, (uint32_t)(quad >> 32), d.site, LD_DROP_STREAM};
+  philox4x32_10(c, (uint32_t)d.seed, (uint32_t)(d.seed >> 32));
+  return f32x4{c[0] >= d.thr ? d.inv_keep : 0.f, c[1] >= d.thr ? d.inv_keep : 0.f,
+               c[2] >= d.thr ? d.inv_keep : 0.f, c[3] >= d.thr ? d.inv_keep : 0.f};
+}
+// Row sites ([rows, width] activations, width a multiple of 128): the quad of element (row, col) holds
+// the four columns {b, b + 32, b + 64, b + 96} of its 128-column block - what one lane of a GEMM
+// epilogue owns - and the element is component (col >> 5) & 3 of it.
+__device__ __forceinline__ uint64_t drop_row_quad(const DropSite& d, int row, int col, int width) {
+  return (uint64_t)(d.row_offset + row) * (uint64_t)(width >> 2) + (uint64_t)((col >> 7) * 32 + (col & 31));
+}
+__device__ __forceinline__ float drop_row_scale(const DropSite& d, int row, int col, int width) {
+  return drop_scale4(d, drop_row_quad(d, row, col, width))[(col >> 5) & 3];
+}
+// Attention site: element (query atom, head, key index j within the molecule) -> quad of four
+// consecutive keys; the element is component j & 3.
+__device__ __forceinline__ uint64_t drop_att_quad(const DropSite& d, int q_atom, int head, int j) {
+  return ((uint64_t)(d.row_offset + q_atom) * 8u + (uint64_t)head) * 32u + (uint64_t)(j >> 2);
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -62,7 +62,9 @@ struct EpiEmbed {
 // adaLN-gated residual, model1.py:295 / :300:  x = resid + gate[mol] * (acc + bias),
 // optionally followed by the NEXT modulated pre-norm (model1.py:293 / :298)
 //   xn = LN(x; eps 1e-6, no affine) * (1 + scale[mol]) + shift[mol].
-template <bool LNMOD>
+// DROP (column-split form only): acc + bias is multiplied by the dropout mask of site `drop` first
+// (model1.py:272: Dropout on the FFN output); proj_out then keeps the masked value.
+template <bool LNMOD, bool DROP = false>
 struct EpiGate {
   int M;
   const float* bias;
@@ -73,7 +75,9 @@ struct EpiGate {
   float* X;                                 // [M,256]
   float* XN;                                // [M,256] (LNMOD)
   float* proj_out;                          // nullable: acc + bias (kept for backward)
+  DropSite drop;                            // used with DROP only
   __device__ __forceinline__ void operator()(f32x16 (&acc)[8], int row0, int by, int lane) const {
+    static_assert(!DROP, "dropout epilogue: column-split kernels only");
     const int c0 = lane & 31;
     float bv[8];
 #pragma unroll
@@ -153,9 +157,11 @@ struct EpiGate {
         const int r = hb * 8 + i;
         const int row = row0 + G_ROW(r, lane);
         float s = 0.f;
+        f32x4 ms = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) ms = drop_scale4(drop, drop_row_quad(drop, row, cb, 256));
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-          const float pr = acc[ct][r] + bv[ct];
+          const float pr = DROP ? (acc[ct][r] + bv[ct]) * ms[ct] : acc[ct][r] + bv[ct];
           if (SAVE && row < M) proj_out[(size_t)row * 256 + cb + ct * 32] = pr;
           acc[ct][r] = rs[ct][i] + gt[ct][i] * pr;
           s += acc[ct][r];

@@ -62,4 +62,11 @@ int run_time_rows(const float* const* w, const float* t, int n_rows, float* tf, 
 int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
                 const float* t, const int32_t* t_index_dev, const float* properties, int flags,
                 float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s,
-                FwdProbe* probe = nullptr, SplitCache* split = nullptr);
+                FwdProbe* probe = nullptr, SplitCache* split = nullptr, const ligdiff_dropout* drop = nullptr);
+
+// Device-side description of one dropout site of a call (common.h: DropSite); thr == 0 when the
+// call has no dropout or the site's p is 0.  Returns false for a probability outside [0, 1).
+struct DropSite;
+bool make_drop_site(const ligdiff_dropout* d, int layer, int kind, DropSite* out);
+// True when the A/B environment switches left the default (column-split) GEMM kernels in place.
+int check_dropout(const ligdiff_dropout* d);

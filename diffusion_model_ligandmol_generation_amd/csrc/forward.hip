@@ -144,6 +144,66 @@ static size_t split_region_bytes() {
   return bytes;
 }
 
+// ------------------------------------------------------------------ dropout sites
+bool make_drop_site(const ligdiff_dropout* d, int layer, int kind, DropSite* out) {
+  memset(out, 0, sizeof *out);
+  if (d == nullptr) return true;
+  const float p = kind == LIGDIFF_DROP_ATTENTION ? d->p_attention[layer]
+                  : kind == LIGDIFF_DROP_FFN_HIDDEN ? d->p_ffn_hidden[layer] : d->p_ffn_out[layer];
+  if (!(p >= 0.0f && p < 1.0f)) return false;
+  if (p == 0.0f) return true;
+  out->seed = d->seed;
+  out->row_offset = d->atom_offset;
+  out->site = (uint32_t)(layer * 4 + kind);
+  const double t = (double)p * 4294967296.0;
+  out->thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  if (out->thr == 0u) out->thr = 1u;
+  out->inv_keep = 1.0f / (1.0f - p);
+  return true;
+}
+int check_dropout(const ligdiff_dropout* d) {
+  if (d == nullptr) return LIGDIFF_OK;
+  if (d->atom_offset < 0) return LIGDIFF_ERR_ARG;
+  bool any = false;
+  for (int l = 0; l < 3; ++l)
+    for (int k = 0; k < 3; ++k) {
+      DropSite ds;
+      if (!make_drop_site(d, l, k, &ds)) return LIGDIFF_ERR_ARG;
+      any = any || ds.thr != 0u;
+    }
+  if (any && !use_cs()) return LIGDIFF_ERR_ARG;   // only the column-split GEMM epilogues carry the masks
+  return LIGDIFF_OK;
+}
+
+__global__ void k_dropout_mask(DropSite d, int kind, int64_t n_atoms, float* __restrict__ out) {
+  const int width = kind == LIGDIFF_DROP_FFN_OUT ? 256 : 1024;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_atoms * width) return;
+  const int row = (int)(i / width), col = (int)(i % width);
+  float v = 1.0f;
+  if (d.thr != 0u) {
+    if (kind == LIGDIFF_DROP_ATTENTION) {
+      const int head = col >> 7, j = col & 127;
+      v = drop_scale4(d, drop_att_quad(d, row, head, j))[j & 3];
+    } else {
+      v = drop_row_scale(d, row, col, width);
+    }
+  }
+  out[i] = v;
+}
+extern "C" int ligdiff_dropout_mask(const ligdiff_dropout* dropout, int32_t layer, int32_t kind, int64_t n_atoms,
+                                    float* out, void* stream) {
+  if (!dropout || layer < 0 || layer > 2 || kind < 0 || kind > 2 || n_atoms <= 0 || !out || n_atoms >= (1LL << 30))
+    return LIGDIFF_ERR_ARG;
+  DropSite ds;
+  if (!make_drop_site(dropout, layer, kind, &ds)) return LIGDIFF_ERR_ARG;
+  const int width = kind == LIGDIFF_DROP_FFN_OUT ? 256 : 1024;
+  hipLaunchKernelGGL(k_dropout_mask, dim3(ceil_div(n_atoms * width, 256)), dim3(256), 0, (hipStream_t)stream, ds, kind,
+                     n_atoms, out);
+  LD_CHECK_LAUNCH();
+  return LIGDIFF_OK;
+}
+
 // ------------------------------------------------------------------ workspace layout
 void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
   memset(L, 0, sizeof *L);
@@ -216,7 +276,7 @@ int run_time_rows(const float* const* w, const float* t, int n_rows, float* tf, 
 int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
                 const float* t, const int32_t* t_index_dev, const float* properties, int flags,
                 float* atom_pred, float* pos_pred, float* prop_pred, char* ws, hipStream_t s, FwdProbe* probe,
-                SplitCache* split) {
+                SplitCache* split, const ligdiff_dropout* drop) {
   const int N = (int)g->n_atoms, E = (int)g->n_edges, B = g->n_mols;
   // PB(label) ... PE(): brackets one launch with the probe's events when its label matches
   char lbl[48];
@@ -473,14 +533,25 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       const float* qkv_l = F(L.qkv[l]);
       float* att_l = F(L.att[l]);
       float* lse_l = S(L.lse[l]);
-      if (!att_lds && tk == 1)
-        hipLaunchKernelGGL(k_attention_reg<1>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B);
+      DropSite da;
+      if (!make_drop_site(drop, l, LIGDIFF_DROP_ATTENTION, &da)) return LIGDIFF_ERR_ARG;
+      if (da.thr != 0u) {   // train-mode dropout on the probabilities (always the register kernel)
+        if (tk == 1)
+          hipLaunchKernelGGL((k_attention_reg<1, true>), dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B, da);
+        else if (tk == 2)
+          hipLaunchKernelGGL((k_attention_reg<2, true>), dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B, da);
+        else if (tk == 3)
+          hipLaunchKernelGGL((k_attention_reg<3, true>), dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B, da);
+        else
+          hipLaunchKernelGGL((k_attention_reg<4, true>), dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B, da);
+      } else if (!att_lds && tk == 1)
+        hipLaunchKernelGGL(k_attention_reg<1>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B, da);
       else if (!att_lds && tk == 2)
-        hipLaunchKernelGGL(k_attention_reg<2>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B);
+        hipLaunchKernelGGL(k_attention_reg<2>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B, da);
       else if (!att_lds && tk == 3)
-        hipLaunchKernelGGL(k_attention_reg<3>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B);
+        hipLaunchKernelGGL(k_attention_reg<3>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B, da);
       else if (!att_lds)
-        hipLaunchKernelGGL(k_attention_reg<4>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B);
+        hipLaunchKernelGGL(k_attention_reg<4>, dim3(blocks), dim3(256), 0, s, qkv_l, g->mol_ptr, att_l, lse_l, B, da);
       else if (tk == 1)
         hipLaunchKernelGGL(k_attention_mfma<1>, dim3(blocks), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]), S(L.lse[l]), B);
       else if (tk == 2)
@@ -499,23 +570,49 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       launch_gemm_plain<8>(gc, F(L.att[l]), 256, e, 1, s);
       PE();
     }
+    DropSite dh, dout;
+    if (!make_drop_site(drop, l, LIGDIFF_DROP_FFN_HIDDEN, &dh) || !make_drop_site(drop, l, LIGDIFF_DROP_FFN_OUT, &dout))
+      return LIGDIFF_ERR_ARG;
+    if ((dh.thr != 0u || dout.thr != 0u) && !use_cs()) return LIGDIFF_ERR_ARG;
     PB("dit%d.ffn_up", l);
-    gemm_bias_act<ACT_GELU, false>(F(L.xn2[l]), 256, N, 256, w[W_DIT(l, DIT_FF0_W)], 256, w[W_DIT(l, DIT_FF0_B)], 4,
-                                   F(L.ffh[l]), 1024, nullptr, s, S(L.ffh_pre[l]));
+    if (dh.thr != 0u) {   // ffh = Dropout(GELU(xn2 W0^T + b)), model1.py:268-270
+      GemmCore gc = core_blocks(N, 256, 256, w[W_DIT(l, DIT_FF0_W)], 256, 4, 256);
+      EpiBiasAct<8, ACT_GELU, false, true> e;
+      memset(&e, 0, sizeof e);
+      e.M = N; e.n_valid = 256; e.col_block = 256; e.C = F(L.ffh[l]); e.ldc = 1024; e.alpha = 1.0f;
+      e.pre_out = S(L.ffh_pre[l]); e.drop = dh;
+      for (int i = 0; i < 4; ++i) e.bias[i] = w[W_DIT(l, DIT_FF0_B)] + (size_t)i * 256;
+      launch_gemm_cs(gc, APtrPlain{F(L.xn2[l]), 256}, e, 4, s);
+    } else {
+      gemm_bias_act<ACT_GELU, false>(F(L.xn2[l]), 256, N, 256, w[W_DIT(l, DIT_FF0_W)], 256, w[W_DIT(l, DIT_FF0_B)], 4,
+                                     F(L.ffh[l]), 1024, nullptr, s, S(L.ffh_pre[l]));
+    }
     PE();
     {  // x2 = x1 + gate_mlp * (ffh W3^T + b); next layer's xn1 fused
       GemmCore gc = core_blocks(N, 1024, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1, 256);
       if (l < 2) {
-        EpiGate<true> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l + 1]), 0, 256,
-                        g->atom_mol, F(L.x2[l]), F(L.xn1[l + 1]), S(L.fproj[l])};
         PB("dit%d.ffn_down", l);
-        launch_gemm_plain<8>(gc, F(L.ffh[l]), 1024, e, 1, s);
+        if (dout.thr != 0u) {   // Dropout on the FFN output before the gated residual, model1.py:271-272
+          EpiGate<true, true> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l + 1]), 0, 256,
+                                g->atom_mol, F(L.x2[l]), F(L.xn1[l + 1]), S(L.fproj[l]), dout};
+          launch_gemm_cs(gc, APtrPlain{F(L.ffh[l]), 1024}, e, 1, s);
+        } else {
+          EpiGate<true> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l + 1]), 0, 256,
+                          g->atom_mol, F(L.x2[l]), F(L.xn1[l + 1]), S(L.fproj[l])};
+          launch_gemm_plain<8>(gc, F(L.ffh[l]), 1024, e, 1, s);
+        }
         PE();
       } else {
-        EpiGate<false> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l]), 0, 256,
-                         g->atom_mol, F(L.x2[l]), nullptr, S(L.fproj[l])};
         PB("dit%d.ffn_down", l);
-        launch_gemm_plain<8>(gc, F(L.ffh[l]), 1024, e, 1, s);
+        if (dout.thr != 0u) {
+          EpiGate<false, true> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l]), 0, 256,
+                                 g->atom_mol, F(L.x2[l]), nullptr, S(L.fproj[l]), dout};
+          launch_gemm_cs(gc, APtrPlain{F(L.ffh[l]), 1024}, e, 1, s);
+        } else {
+          EpiGate<false> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l]), 0, 256,
+                           g->atom_mol, F(L.x2[l]), nullptr, S(L.fproj[l])};
+          launch_gemm_plain<8>(gc, F(L.ffh[l]), 1024, e, 1, s);
+        }
         PE();
       }
     }

@@ -191,7 +191,9 @@ __device__ __forceinline__ float apply_act(float v) {
 
 // C[row, by*col_block + col] = act(acc + bias);  optional C2 = silu(C);
 // optional ACCUM: C += value (used by split reductions that run serially).
-template <int NT, int ACT, bool DUAL_SILU>
+// DROP (column-split form only): the activation's output is multiplied by the dropout mask of
+// site `drop` before it is stored (model1.py:270: Dropout after the FFN's GELU); pre_out keeps u.
+template <int NT, int ACT, bool DUAL_SILU, bool DROP = false>
 struct EpiBiasAct {
   int M; int n_valid; int col_block;
   const float* bias[8];
@@ -199,6 +201,7 @@ struct EpiBiasAct {
   float* C2;
   float alpha;     // scales acc before bias (1.0f normally)
   float* pre_out;  // nullable: u = alpha*acc + bias before the activation (kept for backward)
+  DropSite drop;   // used with DROP only
   __device__ __forceinline__ void operator()(f32x16 (&acc)[NT], int row0, int by, int lane) const {
     const int c0 = lane & 31;
     const float* b = bias[by];
@@ -258,6 +261,12 @@ struct EpiBiasAct {
         } else {
 #pragma unroll
           for (int ct = 0; ct < NW; ++ct) v[ct] = apply_act<ACT>(u[ct]);
+        }
+        if (DROP) {
+          static_assert(!DROP || NW == 4, "dropout epilogue: 256-column blocks only");
+          const f32x4 ms = drop_scale4(drop, drop_row_quad(drop, row, by * col_block + c0, ldc));
+#pragma unroll
+          for (int ct = 0; ct < NW; ++ct) v[ct] *= ms[ct & 3];
         }
 #pragma unroll
         for (int ct = 0; ct < NW; ++ct) {

@@ -167,6 +167,8 @@ struct EpiBwdStore {
   float* C; int ldc;
   const float* pre; int ldp;
   float alpha;
+  DropSite drop;   // thr != 0 (column-split form only): C's activation was dropout-masked in the forward
+                   // pass after its nonlinearity; the gradient takes the same mask (row width N)
   __device__ __forceinline__ void operator()(f32x16 (&acc)[NT], int row0, int col_blk, int lane) const {
     const int c0 = lane & 31;
 #pragma unroll
@@ -207,9 +209,11 @@ struct EpiBwdStore {
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + G_ROW(r, lane);
       if (row < M) {
+        f32x4 ms = {1.f, 1.f, 1.f, 1.f};
+        if (drop.thr != 0u) ms = drop_scale4(drop, drop_row_quad(drop, row, cb, N));
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-          float v = acc[ct][r] * alpha;
+          float v = acc[ct][r] * alpha * ms[ct];
           if (MUL == MUL_SILU_GRAD) v *= silu_grad(pv[ct][r]);
           if (MUL == MUL_GELU_GRAD) v *= gelu_exact_grad(pv[ct][r]);
           if (ACCUM) v += old[ct][r];

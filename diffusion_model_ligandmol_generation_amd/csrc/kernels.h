@@ -430,11 +430,14 @@ __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict_
 // the operand registers.  For O^T = V^T P^T lane (d, h) needs V[j(r, h), d] for its 16 keys: 16 dword
 // loads, each a coalesced 128-B row segment per lane half.  Rows beyond n are clamped to the last atom
 // (their scores are masked to -inf, their probabilities are exactly 0).
-template <int TK>
+// DROP: the normalised probabilities are multiplied by the dropout mask of site `drop` before the
+// product with V (nn.MultiheadAttention in train mode, model1.py:263-267); the row sum l and the
+// saved log-sum-exp stay those of the unmasked softmax.
+template <int TK, bool DROP = false>
 __global__ __launch_bounds__(256) void k_attention_reg(const float* __restrict__ qkv,
                                                        const int32_t* __restrict__ mol_ptr,
                                                        float* __restrict__ out, float* __restrict__ lse_out,
-                                                       int n_mols) {
+                                                       int n_mols, DropSite drop = DropSite{}) {
   constexpr int ITEMS = 8 * TK;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = blockIdx.x * 4 + wave;
@@ -500,6 +503,16 @@ __global__ __launch_bounds__(256) void k_attention_reg(const float* __restrict__
       l += p;
     }
   l += __shfl_xor(l, 32);
+  if (DROP) {   // registers 4g..4g+3 of tile t are the keys j = 32 t + 8 g + 4 h + (0..3): one mask quad
+#pragma unroll
+    for (int t = 0; t < TK; ++t)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 ms = drop_scale4(drop, drop_att_quad(drop, a0 + qi, head, t * 32 + gq * 8 + h * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sc[t][gq * 4 + e] *= ms[e];
+      }
+  }
   f32x16 o;
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;

@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ u, int
 __global__ __launch_bounds__(256) void k_gate_bwd(const float* __restrict__ dx, const float* __restrict__ proj,
                                                   const float* __restrict__ mod, int mod_stride, int gate_off,
                                                   const int32_t* __restrict__ mol_ptr, int B, float* __restrict__ dproj,
-                                                  float* __restrict__ dmod) {
+                                                  float* __restrict__ dmod, DropSite drop = DropSite{}) {
+  // drop.thr != 0: proj is the dropout-masked projection the forward pass saved; dproj takes the mask
   __shared__ float sh[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mol = blockIdx.x;
@@ -225,7 +226,12 @@ __global__ __launch_bounds__(256) void k_gate_bwd(const float* __restrict__ dx, 
   for (int a = mol_ptr[mol] + wave; a < mol_ptr[mol + 1]; a += 4) {
     const f32x4 d = *reinterpret_cast<const f32x4*>(dx + (size_t)a * 256 + lane * 4);
     dgate += d * *reinterpret_cast<const f32x4*>(proj + (size_t)a * 256 + lane * 4);
-    *reinterpret_cast<f32x4*>(dproj + (size_t)a * 256 + lane * 4) = d * gate;
+    f32x4 dp = d * gate;
+    if (drop.thr != 0u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dp[e] *= drop_row_scale(drop, a, lane * 4 + e, 256);
+    }
+    *reinterpret_cast<f32x4*>(dproj + (size_t)a * 256 + lane * 4) = dp;
   }
   *reinterpret_cast<f32x4*>(&sh[wave][lane * 4]) = dgate;
   __syncthreads();
@@ -357,11 +363,14 @@ __global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__
 // with Q' = Q / sqrt(32); dQ and dK carry the same factor.  Register r of lane half h is row
 // (r & 3) + 8 (r >> 2) + 4 h of a tile.
 #define GB_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
-template <int TK, int WPB>
+// DROP: the forward pass multiplied the probabilities by the dropout mask Ms of site `drop`
+// (O = (P Ms) V): dV takes P Ms, dP = (dO V^T) Ms, and delta_i = dO_i . O_i is unchanged in form.
+template <int TK, int WPB, bool DROP = false>
 __global__ __launch_bounds__(WPB * 64) void k_attention_bwd_mfma(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                  const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                  const int32_t* __restrict__ mol_ptr,
-                                                                 float* __restrict__ dqkv, int n_mols) {
+                                                                 float* __restrict__ dqkv, int n_mols,
+                                                                 DropSite drop = DropSite{}) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NP = TK * 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -426,6 +435,14 @@ __global__ __launch_bounds__(WPB * 64) void k_attention_bwd_mfma(const float* __
         st = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * s], qreg[s], st, 0, 0, 0);
         dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[2 * s], doreg[s], dpt, 0, 0, 0);
       }
+      if (DROP) {   // registers 4g..4g+3 are four consecutive keys: one mask quad
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 ms = drop_scale4(drop, drop_att_quad(drop, a0 + qi, head, jt * 32 + gq * 8 + h * 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dpt[gq * 4 + e] *= ms[e];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = jt * 32 + GB_ROW(r, h);
@@ -473,8 +490,10 @@ __global__ __launch_bounds__(WPB * 64) void k_attention_bwd_mfma(const float* __
       for (int r = 0; r < 16; ++r) {
         const int i = it * 32 + GB_ROW(r, h);
         const float p = (i < n && kj < n) ? __expf(sm[r] - slse[i]) : 0.f;
-        sm[r] = p;
-        dp[r] = p * (dp[r] - sdel[i]);
+        float ms = 1.0f;
+        if (DROP) ms = drop_scale4(drop, drop_att_quad(drop, a0 + i, head, kj))[kj & 3];
+        sm[r] = p * ms;
+        dp[r] = p * (dp[r] * ms - sdel[i]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -132,7 +132,7 @@ class ScoreNetworkEngine:
         return self._ws
 
     def forward(self, graph, x, pos, t, properties=None, null_cond=False, want_props=True, save=False,
-                workspace=None, t_index=None, keep_state=False):
+                workspace=None, t_index=None, keep_state=False, dropout=None):
         """ligdiff_forward on the current stream.  t: [B] float tensor (or [1], applied to
         every molecule); alternatively t_index, a device int32 scalar holding the step.
         Returns atom_pred, pos_pred, prop_pred (None if not wanted)."""
@@ -178,10 +178,11 @@ class ScoreNetworkEngine:
         pos_pred = torch.empty(N, 3, dtype=torch.float32, device=self.device)
         prop_pred = torch.empty(B, 15, dtype=torch.float32, device=self.device) if want_props else None
         with torch.cuda.device(self.device):
-            rc = self.lib.ligdiff_forward(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(t), _ptr(t_index),
-                                          _ptr(properties) if (properties is not None and not null_cond) else None,
-                                          flags, _ptr(atom_pred), _ptr(pos_pred), _ptr(prop_pred), _ptr(ws),
-                                          ws.numel(), _stream())
+            rc = self.lib.ligdiff_forward_train(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(t), _ptr(t_index),
+                                                _ptr(properties) if (properties is not None and not null_cond) else None,
+                                                flags, _ptr(atom_pred), _ptr(pos_pred), _ptr(prop_pred), _ptr(ws),
+                                                ws.numel(), _stream(),
+                                                C.byref(dropout) if dropout is not None else None)
         check(rc, "ligdiff_forward")
         self.last_forward = (ws, flags) if keep_state else None   # for consistency() right after this call
         return atom_pred, pos_pred, prop_pred
@@ -208,6 +209,18 @@ class ScoreNetworkEngine:
                                                 label.encode(), int(reps), C.byref(ms))
         check(rc, f"ligdiff_forward_timed({label})")
         return float(ms.value)
+
+    def dropout_mask(self, dropout, layer, kind, n_atoms):
+        """The mask scales (0 or 1 / (1 - p)) the library applies at one dropout site for atoms
+        [0, n_atoms) of a call made with ``dropout`` (ligdiff_dropout_mask): kind 0 attention
+        probabilities [n_atoms, 8, 128] (query atom, head, key index in its molecule), 1 FFN hidden
+        [n_atoms, 1024], 2 FFN output [n_atoms, 256]."""
+        shape = {0: (n_atoms, 8, 128), 1: (n_atoms, 1024), 2: (n_atoms, 256)}[kind]
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(self.lib.ligdiff_dropout_mask(C.byref(dropout), int(layer), int(kind), int(n_atoms), _ptr(out), _stream()),
+                  "ligdiff_dropout_mask")
+        return out
 
     def time_backward_launch(self, graph, x, pos, t, wide_dw_index, reps=5):
         """Mean duration in ms of one wide weight-gradient launch of the backward pass in situ

@@ -85,10 +85,37 @@ class ResearchAccurateDiffusionModel(nn.Module):
             self._engine = ScoreNetworkEngine(self)
         return self._engine
 
+    def dropout_spec(self, atom_offset=0, seed=None):
+        """The train-mode dropout of one forward / backward pair as the library takes it (struct
+        ligdiff_dropout), or None in eval mode or when every probability is 0.  The probabilities are
+        read from the modules the reference configures (model1.py:263-274): ``attention.dropout`` and
+        the two ``nn.Dropout`` of ``ff_network``.  seed None: a fresh key from torch's global generator
+        (so torch.manual_seed makes a run repeatable).  atom_offset: global index of the batch's first
+        atom (a data-parallel shard passes the atoms that precede it; the mask then equals the
+        unsharded batch's)."""
+        if not self.training:
+            return None
+        from ._lib import Dropout
+        d = Dropout()
+        any_p = False
+        for l, lyr in enumerate(self.dit_layers):
+            d.p_attention[l] = float(lyr.attention.dropout)
+            d.p_ffn_hidden[l] = float(lyr.ff_network[2].p)
+            d.p_ffn_out[l] = float(lyr.ff_network[4].p)
+            any_p = any_p or d.p_attention[l] > 0 or d.p_ffn_hidden[l] > 0 or d.p_ffn_out[l] > 0
+        if not any_p:
+            return None
+        d.seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item()) if seed is None else int(seed)
+        d.atom_offset = int(atom_offset)
+        return d
+
     def forward(self, data, t, properties=None, classifier_free_guidance=False):
         """model1.py:699-755.  ``data`` is any object with .x [N,119], .pos [N,3],
         .edge_index [2,E] int64 and .batch [N] int64 (sorted).  Returns
         (atom_pred [N,119], pos_pred [N,3], prop_pred [B,15], consistency_outputs).
+
+        Train mode applies the attention layers' dropout (see ``dropout_spec``); ``data.dropout_seed``
+        and ``data.atom_offset``, when present, fix the mask's key and the batch's global position.
 
         consistency_outputs: None in eval mode; in train mode the MolDiff consistency module's
         (atom_logits, bond_logits, valency_constrained, adjacency_matrix) as model1.py:750-753

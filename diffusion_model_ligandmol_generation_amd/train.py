@@ -120,27 +120,37 @@ class ResearchAccurateTrainer:
                 properties[null_rand < 0.1] = 0.0
             properties = properties.contiguous()
 
+        # global counts for data-parallel means, and this shard's position in the global batch
+        n_atoms_g, n_mols_g, mol_off, atom_off = N, B, 0, 0
+        if self.group is not None:
+            import torch.distributed as dist
+            cdev = dev if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+            seed_here = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
+            cnt = torch.tensor([N, B, seed_here], device=cdev, dtype=torch.int64)
+            allc = [torch.zeros_like(cnt) for _ in range(self.world)]
+            dist.all_gather(allc, cnt, group=self.group)
+            allc = torch.stack(allc).cpu()
+            n_atoms_g, n_mols_g = int(allc[:, 0].sum()), int(allc[:, 1].sum())
+            mol_off, atom_off = int(allc[:self.rank, 1].sum()), int(allc[:self.rank, 0].sum())
+            shared_seed = int(allc[0, 2])     # every rank keys its dropout masks with rank 0's draw
+
         class _Data:
             pass
 
         d = _Data()
         d.x, d.pos, d.edge_index, d.batch, d._ligdiff_graph = x, pre_pos, batch.edge_index, batch.batch, graph
+        # dropout masks are keyed by (seed, global atom index): with the same seed on every rank the sharded
+        # step draws the mask of the unsharded batch
+        d.atom_offset = atom_off
+        if "dropout_seed" in draws:
+            d.dropout_seed = int(draws["dropout_seed"])
+        elif self.group is not None:
+            d.dropout_seed = shared_seed
         # the consistency module's outputs reach no loss term here (train.py:519, :543, :559, :583), so the
         # training step does not spend an O(sum n^2) pass and an [N,N] tensor on them
         d.skip_consistency = not getattr(self, "run_consistency", False)
         atom_pred, pos_pred, prop_pred, _ = model(d, c_noise, properties)               # train.py:349
 
-        # global counts for data-parallel means
-        n_atoms_g, n_mols_g, mol_off = N, B, 0
-        if self.group is not None:
-            import torch.distributed as dist
-            cdev = dev if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
-            cnt = torch.tensor([N, B], device=cdev, dtype=torch.int64)
-            allc = [torch.zeros_like(cnt) for _ in range(self.world)]
-            dist.all_gather(allc, cnt, group=self.group)
-            allc = torch.stack(allc).cpu()
-            n_atoms_g, n_mols_g = int(allc[:, 0].sum()), int(allc[:, 1].sum())
-            mol_off = int(allc[:self.rank, 1].sum())
         rot_mols = max(0, min(2, n_mols_g) - mol_off)
         rot_mols = min(rot_mols, B)
         st = _Ctx(eng=eng, graph=graph, pos=pos, noise=noise, noisy=noisy, coef=coef, props=properties,

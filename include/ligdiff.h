@@ -157,6 +157,41 @@ int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, con
                     float* prop_pred, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * Train-mode dropout of the attention layers (model1.py:263-274: nn.MultiheadAttention(dropout=0.1)
+ * on the attention probabilities, nn.Dropout(0.1) after the FFN's GELU and after its second Linear).
+ * A mask element is a pure function of (seed, site, global element index) through Philox4x32-10, so
+ * forward and backward regenerate the same mask from the same struct and a batch sharded over GPUs
+ * draws the mask of the unsharded batch (atom_offset = global index of this call's first atom).
+ * Kept elements are scaled by 1 / (1 - p), as torch.nn.functional.dropout does; p = 0 disables a
+ * site.  The random stream is not torch's: parity with the reference holds for a given mask, which
+ * ligdiff_dropout_mask exports.
+ * ------------------------------------------------------------------------------- */
+typedef struct ligdiff_dropout {
+  uint64_t seed;            /* Philox key of this forward / backward pair                         */
+  int64_t atom_offset;      /* global index of atom 0 of this call                                */
+  float p_attention[3];     /* per attention layer: probabilities, FFN hidden, FFN output         */
+  float p_ffn_hidden[3];
+  float p_ffn_out[3];
+} ligdiff_dropout;
+
+enum ligdiff_dropout_kind { LIGDIFF_DROP_ATTENTION = 0, LIGDIFF_DROP_FFN_HIDDEN = 1, LIGDIFF_DROP_FFN_OUT = 2 };
+
+/* ligdiff_forward / ligdiff_backward with dropout (NULL = none: identical to the plain entry points).
+ * Needs the default GEMM kernels (no LIGDIFF_GEMM_V1 / LIGDIFF_GEMM_NOCS in the environment). */
+int ligdiff_forward_train(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                          const float* pos, const float* t, const int32_t* t_index_dev,
+                          const float* properties, int flags, float* atom_pred, float* pos_pred,
+                          float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
+                          const ligdiff_dropout* dropout);
+
+/* Writes the mask scale (0 or 1 / (1 - p)) of every element of one dropout site for atoms
+ * [0, n_atoms) of a call made with `dropout`: kind LIGDIFF_DROP_FFN_HIDDEN -> out [n_atoms, 1024],
+ * LIGDIFF_DROP_FFN_OUT -> out [n_atoms, 256], LIGDIFF_DROP_ATTENTION -> out [n_atoms, 8, 128] indexed
+ * (query atom, head, key index within the query's molecule). */
+int ligdiff_dropout_mask(const ligdiff_dropout* dropout, int32_t layer, int32_t kind, int64_t n_atoms,
+                         float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Score-network backward.  Replaces autograd's reverse pass through model1.py:699-755
  * (train.py:195).  `fwd_workspace` must be the workspace of a ligdiff_forward call made
  * with LIGDIFF_FWD_SAVE_FOR_BACKWARD (per-molecule t, same graph / x / pos / properties /
@@ -171,6 +206,13 @@ int ligdiff_backward(const float* const* weights, float* const* grads, const lig
                      const float* x, const float* pos, const float* properties, int flags,
                      const float* d_atom, const float* d_pos, const float* d_prop,
                      const void* fwd_workspace, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ligdiff_backward for a forward pass made by ligdiff_forward_train with the same `dropout`. */
+int ligdiff_backward_train(const float* const* weights, float* const* grads, const ligdiff_graph* graph,
+                           const float* x, const float* pos, const float* properties, int flags,
+                           const float* d_atom, const float* d_pos, const float* d_prop,
+                           const void* fwd_workspace, void* workspace, size_t workspace_bytes, void* stream,
+                           const ligdiff_dropout* dropout);
 
 /* Measurement hook (no counterpart in the reference): runs `reps` backward passes with the arguments
  * of ligdiff_backward (gradients keep accumulating into `grads`: pass throw-away buffers) and

@@ -28,14 +28,16 @@ def _mean_pool(v, batch, B):
 
 
 def loss_step(sd, x, pos, edge_index, batch, u, noise, properties=None, null_rand=None,
-              training=True, max_atoms=100, sigma_min=0.002, sigma_max=80.0, sigma_data=0.5, shard=None):
+              training=True, max_atoms=100, sigma_min=0.002, sigma_max=80.0, sigma_data=0.5, shard=None,
+              dropout=None):
     """Returns (losses dict of 0-dim tensors, aux dict).  B >= 2 (see edm_scalings).
 
     shard=(n_atoms_global, n_mols_global, rot_mols): evaluate ONE data-parallel shard's
     share of the global-batch loss - every mean divides by the global count and the
     first-two-molecules distance term only covers this shard's rot_mols leading molecules -
     so that the shard losses (and their gradients) of all ranks sum to the unsharded
-    result.  Used by the tests of the multi-GPU decomposition; not a reference feature."""
+    result.  Used by the tests of the multi-GPU decomposition; not a reference feature.
+    dropout: the attention layers' train-mode masks (see score_network_forward)."""
     if shard is not None:
         return _loss_step_shard(sd, x, pos, edge_index, batch, u, noise, properties, null_rand, training,
                                 max_atoms, sigma_min, sigma_max, sigma_data, shard)
@@ -52,7 +54,7 @@ def loss_step(sd, x, pos, edge_index, batch, u, noise, properties=None, null_ran
             props = props.clone()
             props[null_rand < 0.1] = 0.0
     atom_pred, pos_pred, prop_pred = score_network_forward(
-        sd, x, pre, edge_index, batch, c_noise, props, max_atoms=max_atoms, pad_to_max_atoms=False)
+        sd, x, pre, edge_index, batch, c_noise, props, max_atoms=max_atoms, pad_to_max_atoms=False, dropout=dropout)
     L, den = loss_terms(atom_pred, pos_pred, prop_pred, pos, noise, noisy, c_skip, c_out, w, batch, props)
     aux = {"sigma": sigma, "denoised_pos": den, "atom_pred": atom_pred, "pos_pred": pos_pred,
            "prop_pred": prop_pred}

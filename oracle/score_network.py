@@ -75,12 +75,16 @@ def e3_layer(sd, prefix, h, pos, edge_index):
     return hn, dpos, m
 
 
-def dit_layer(sd, prefix, x, t_emb, key_pad, num_heads):
+def dit_layer(sd, prefix, x, t_emb, key_pad, num_heads, drop=None):
     """model1.py:279-302 on a dense [B, M, H] batch; key_pad [B, M] is True at padding.
 
-    nn.MultiheadAttention semantics (batch_first, eval): packed in_proj, per-head scaled
-    dot product with padded keys at -inf, out_proj.
+    nn.MultiheadAttention semantics (batch_first): packed in_proj, per-head scaled dot product
+    with padded keys at -inf, out_proj.  drop (train mode, model1.py:263-274): dict of mask SCALES
+    (0 or 1 / (1 - p), what torch.nn.functional.dropout multiplies by) - 'att' [B, heads, M, M] on the
+    softmax probabilities, 'ffn_hidden' [B, M, 4H] after the GELU, 'ffn_out' [B, M, H] on the FFN
+    output; a missing key means no dropout at that site.
     """
+    drop = drop or {}
     B, M, H = x.shape
     dh = H // num_heads
     params = _lin(sd, prefix + ".adaLN_modulation.1", F.silu(t_emb))
@@ -99,11 +103,18 @@ def dit_layer(sd, prefix, x, t_emb, key_pad, num_heads):
     if key_pad is not None:
         s = s.masked_fill(key_pad[:, None, None, :], float("-inf"))
     p = torch.softmax(s, dim=-1)
+    if "att" in drop:
+        p = p * drop["att"]
     o = (p @ v).transpose(1, 2).reshape(B, M, H)
     o = _lin(sd, prefix + ".attention.out_proj", o)
     x = x + g_a.unsqueeze(1) * o
     xn = ln(x) * (1.0 + sc_m.unsqueeze(1)) + sh_m.unsqueeze(1)
-    ff = _lin(sd, prefix + ".ff_network.3", F.gelu(_lin(sd, prefix + ".ff_network.0", xn)))
+    hid = F.gelu(_lin(sd, prefix + ".ff_network.0", xn))
+    if "ffn_hidden" in drop:
+        hid = hid * drop["ffn_hidden"]
+    ff = _lin(sd, prefix + ".ff_network.3", hid)
+    if "ffn_out" in drop:
+        ff = ff * drop["ffn_out"]
     return x + g_m.unsqueeze(1) * ff
 
 
@@ -115,8 +126,13 @@ def _head(sd, prefix, h):
 
 def score_network_forward(sd, x, pos, edge_index, batch, t, properties=None,
                           classifier_free_guidance=False, max_atoms=100, num_heads=8,
-                          pad_to_max_atoms=True, return_intermediates=False):
-    """model1.py:699-755 in eval mode (no dropout, no consistency module).
+                          pad_to_max_atoms=True, return_intermediates=False, dropout=None):
+    """model1.py:699-755 without the consistency module; eval mode unless ``dropout`` is given.
+
+    dropout: one dict per attention layer with the mask scales of its three dropout sites in
+    RAGGED form - 'att' [N, heads, K] (query atom, head, key index within the atom's molecule; K >=
+    the largest molecule), 'ffn_hidden' [N, 4H], 'ffn_out' [N, H] - as ligdiff_dropout_mask exports
+    them; they are scattered into the dense layout here.
 
     pad_to_max_atoms=True reproduces the reference's to_dense_batch(max_num_nodes=
     max_atoms) layout (model1.py:728); False pads only to the longest molecule, which is
@@ -159,7 +175,19 @@ def score_network_forward(sd, x, pos, edge_index, batch, t, properties=None,
     else:
         t_b = t_emb[0].repeat(B, 1)                            # model1.py:729-733
     for l in range(n_dit):
-        dense = dit_layer(sd, f"dit_layers.{l}", dense, t_b, ~mask, num_heads)
+        drop = None
+        if dropout is not None:
+            drop = {}
+            for key, val in dropout[l].items():
+                if key == "att":
+                    d = val.new_ones(B, M, val.shape[1], M)
+                    d[batch, slot] = val[:, :, :M] if val.shape[2] >= M else F.pad(val, (0, M - val.shape[2]), value=1.0)
+                    drop[key] = d.permute(0, 2, 1, 3)                  # [B, heads, M(query), M(key)]
+                else:
+                    d = val.new_ones(B, M, val.shape[1])
+                    d[batch, slot] = val
+                    drop[key] = d
+        dense = dit_layer(sd, f"dit_layers.{l}", dense, t_b, ~mask, num_heads, drop)
     h = dense[mask]
     inter["h_dit"] = h
     atom_pred = _head(sd, "atom_output", h)

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import golden, seed0_model
+from conftest import golden, no_dropout, seed0_model
 
 pytestmark = pytest.mark.gpu
 
@@ -49,7 +49,7 @@ def _worker(rank, world, port, q):
     from diffusion_model_ligandmol_generation_amd.parallel import shard_ranges
     from diffusion_model_ligandmol_generation_amd.train import ResearchAccurateTrainer
     torch.cuda.set_device(0)
-    model = copy.deepcopy(seed0_model()).cuda().train()
+    model = no_dropout(copy.deepcopy(seed0_model())).cuda().train()
     tr = ResearchAccurateTrainer(model, [], [], [], process_group=dist.group.WORLD)
     t = _load()
     sizes = np.bincount(t["batch"].numpy()).tolist()
@@ -64,7 +64,7 @@ def test_two_rank_step_equals_single_process_step():
     from diffusion_model_ligandmol_generation_amd.train import ResearchAccurateTrainer
     t = _load()
     B = int(t["batch"].max()) + 1
-    tr = ResearchAccurateTrainer(copy.deepcopy(seed0_model()).cuda().train(), [], [], [])
+    tr = ResearchAccurateTrainer(no_dropout(copy.deepcopy(seed0_model())).cuda().train(), [], [], [])
     ref_loss, ref = _run(tr, t, 0, B)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -16,7 +16,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle
-from conftest import seed0_model
+from conftest import no_dropout, seed0_model
 
 pytestmark = pytest.mark.gpu
 
@@ -49,16 +49,12 @@ def _data():
     return t
 
 
-def _model_without_dropout():
-    """Train-mode model with every dropout probability at 0 (as the loss fixtures were taken): a dropout
-    mask is keyed by the atom's position in its rank's batch, so a sharded step and the single-process
-    step only agree without it."""
-    model = copy.deepcopy(seed0_model()).cuda().train()
-    for lyr in model.dit_layers:
-        lyr.attention.dropout = 0.0
-        lyr.ff_network[2].p = 0.0
-        lyr.ff_network[4].p = 0.0
-    return model
+def _model(dropout):
+    """Train-mode model, with the reference's dropout (p = 0.1) or with every probability at 0.  The
+    masks are keyed by (seed, global atom index), so with one seed on all ranks a sharded step equals
+    the single-process step also WITH dropout."""
+    m = copy.deepcopy(seed0_model())
+    return (m if dropout else no_dropout(m)).cuda().train()
 
 
 def _run(trainer, t, lo, hi):
@@ -66,7 +62,7 @@ def _run(trainer, t, lo, hi):
     xs, ps, es, bs, prs = shard_batch(t["x"], t["pos"], t["edge_index"], t["batch"], lo, hi, t["props"])
     keep = (t["batch"] >= lo) & (t["batch"] < hi)
     batch = Bag(x=xs.cuda(), pos=ps.cuda(), edge_index=es.contiguous().cuda(), batch=bs.cuda(), properties=prs.cuda())
-    draws = {"u": t["u"][lo:hi], "noise": t["noise"][keep], "null_rand": t["null_rand"][lo:hi]}
+    draws = {"u": t["u"][lo:hi], "noise": t["noise"][keep], "null_rand": t["null_rand"][lo:hi], "dropout_seed": 20240611}
     trainer.optimizer.zero_grad()
     losses = trainer._compute_research_exact_loss(batch, True, draws)
     losses["total_loss"].backward()
@@ -75,14 +71,14 @@ def _run(trainer, t, lo, hi):
     return vals, {n: p.grad.cpu().numpy() for n, p in trainer.model.named_parameters() if p.grad is not None}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, dropout):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from diffusion_model_ligandmol_generation_amd.train import ResearchAccurateTrainer
     torch.cuda.set_device(0)
-    model = _model_without_dropout()
+    model = _model(dropout)
     tr = ResearchAccurateTrainer(model, [], [], [], process_group=dist.group.WORLD)
     lo, hi = RANGES[rank]
     vals, grads = _run(tr, _data(), lo, hi)
@@ -91,17 +87,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_on_ragged_64_atom_shards_equals_single_process_step():
+@pytest.mark.parametrize("dropout", [False, True])
+def test_two_rank_step_on_ragged_64_atom_shards_equals_single_process_step(dropout):
     from diffusion_model_ligandmol_generation_amd.train import ResearchAccurateTrainer
     t = _data()
-    model = _model_without_dropout()
+    model = _model(dropout)
     tr = ResearchAccurateTrainer(model, [], [], [])
     ref_vals, ref = _run(tr, t, 0, len(SIZES))
     assert ref_vals["e3_rotation"] > 0 and ref_vals["pilot_property"] > 0
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 300)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port + int(dropout), q, dropout)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(2)]

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import golden, seed0_model, seed0_state_dict
+from conftest import golden, no_dropout, seed0_model, seed0_state_dict
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-4, 2e-5
@@ -124,7 +124,7 @@ def test_consistency_outputs_match_reference_fixture():
     ligdiff_consistency, against the reference's own outputs (dropout p = 0)."""
     import copy
     f = golden("consistency.npz")
-    m = copy.deepcopy(seed0_model()).cuda()
+    m = no_dropout(copy.deepcopy(seed0_model())).cuda()
     m.moldiff_consistency.max_valences.copy_(torch.from_numpy(f["max_valences"]))
     m.moldiff_consistency.covalent_radii.copy_(torch.from_numpy(f["covalent_radii"]))
     x, pos, ei, b, t = _to(f, ("x", "pos", "edge_index", "batch", "t"))
@@ -147,7 +147,7 @@ def test_consistency_outputs_match_reference_fixture():
 def test_consistency_batched_matches_oracle_ragged():
     """Larger ragged batch (several 32-row tiles of pairs) against the CPU restatement."""
     import copy
-    m = copy.deepcopy(seed0_model()).cuda().train()
+    m = no_dropout(copy.deepcopy(seed0_model())).cuda().train()
     sd = seed0_state_dict()
     c = _random_batch([29, 3, 17, 40, 2, 33], 5)
     x, pos, ei, b = (torch.from_numpy(c[k]) for k in ("x", "pos", "edge_index", "batch"))

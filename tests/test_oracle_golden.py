@@ -201,3 +201,71 @@ def test_oracle_ddpm_sample_takes_caller_edges():
             zx, zp = (next(it), next(it)) if t > 1 else (None, None)
             x2, p2 = oracle.ddpm_step(x2, ex, t, sched, zx), oracle.ddpm_step(p2, ep, t, sched, zp)
     assert torch.equal(x, x2) and torch.equal(pos, p2)
+
+
+def _dropout_fixture_masks(f, tag):
+    """The reference's recorded keep masks (dense, padded to max_atoms) -> per-layer RAGGED mask scales in
+    the form oracle.score_network_forward takes: att [N, 8, M], ffn_hidden [N, 1024], ffn_out [N, 256]."""
+    sizes = f["sizes"].tolist()
+    B, M = len(sizes), int(f["max_atoms"])
+    idx_b = np.repeat(np.arange(B), sizes)
+    idx_s = np.concatenate([np.arange(n) for n in sizes])
+    scale = np.float32(1.0 / 0.9)
+    out = []
+    for l in range(3):
+        att = np.unpackbits(f[f"{tag}_mask_att_{l}"])[:B * 8 * M * M].reshape(B, 8, M, M).astype(np.float32) * scale
+        hid = np.unpackbits(f[f"{tag}_mask_hid_{l}"])[:B * M * 1024].reshape(B, M, 1024).astype(np.float32) * scale
+        ffo = np.unpackbits(f[f"{tag}_mask_out_{l}"])[:B * M * 256].reshape(B, M, 256).astype(np.float32) * scale
+        out.append({"att": torch.from_numpy(att[idx_b, :, idx_s, :].copy()),       # [N, 8, M]
+                    "ffn_hidden": torch.from_numpy(hid[idx_b, idx_s].copy()),
+                    "ffn_out": torch.from_numpy(ffo[idx_b, idx_s].copy())})
+    return out
+
+
+@pytest.mark.parametrize("tag", ["noprop", "prop"])
+def test_oracle_train_mode_dropout_matches_reference(tag):
+    """Trainer loss step in TRAIN mode with dropout p = 0.1 active (model1.py:263-274): the oracle, fed the
+    keep masks the reference's own dropout calls used, reproduces its losses and parameter gradients."""
+    f = golden("dropout.npz")
+    from conftest import seed0_model
+    base = seed0_state_dict(max_atoms=16)
+    pnames = {n for n, _ in seed0_model(max_atoms=16).named_parameters()}
+    sd = {k: (v.requires_grad_(True) if k in pnames else v) for k, v in base.items()}
+    x, pos, ei, b = (torch.from_numpy(f[k]) for k in ("x", "pos", "edge_index", "batch"))
+    props = torch.from_numpy(f["props"]) if tag == "prop" else None
+    masks = _dropout_fixture_masks(f, tag)
+    for m in masks:      # about a tenth of every mask is dropped
+        assert 0.05 < float((m["ffn_hidden"] == 0).float().mean()) < 0.15
+    L, _ = oracle.loss_step(sd, x, pos, ei, b, torch.from_numpy(f[tag + "_u"]), torch.from_numpy(f[tag + "_noise"]),
+                            props, torch.from_numpy(f[tag + "_null_rand"]), max_atoms=16, dropout=masks)
+    n = 0
+    for k, v in L.items():
+        key = f"{tag}_loss_{k}"
+        if key in f.files:
+            ref = float(f[key])
+            assert abs(float(v) - ref) <= 1e-4 * max(abs(ref), 1e-3), (k, float(v), ref)
+            n += 1
+    assert n >= 10
+    L["total_loss"].backward()
+    gsq = 0.0
+    for name in pnames:
+        g = sd[name].grad
+        key = f"{tag}_gradsum_{name}"
+        if key not in f.files:
+            assert g is None or float(g.abs().max()) == 0.0, name
+            continue
+        gsq += float((g.double() ** 2).sum())
+        ref = f[key]
+        assert abs(float((g.double() ** 2).sum()) - ref[2]) <= 2e-3 * ref[2] + 1e-14, name
+        gk = f"{tag}_grad_{name}"
+        if gk in f.files:
+            assert float(np.abs(g.numpy() - f[gk]).max()) <= 2e-4 * float(np.abs(f[gk]).max()) + 1e-10, name
+    assert abs(gsq ** 0.5 - float(f[tag + "_gradnorm"])) <= 1e-3 * float(f[tag + "_gradnorm"])
+    # and the masks matter: without them the gradient of a masked layer is visibly different
+    sd0 = {k: (v.detach().clone().requires_grad_(True) if k in pnames else v) for k, v in base.items()}
+    L0, _ = oracle.loss_step(sd0, x, pos, ei, b, torch.from_numpy(f[tag + "_u"]), torch.from_numpy(f[tag + "_noise"]),
+                             props, torch.from_numpy(f[tag + "_null_rand"]), max_atoms=16)
+    L0["total_loss"].backward()
+    k = "dit_layers.1.ff_network.0.bias"
+    diff = float((sd0[k].grad - sd[k].grad).abs().max()) / float(sd[k].grad.abs().max())
+    assert diff > 0.05, diff
