@@ -36,7 +36,7 @@ class StepArgs(C.Structure):
 class Dropout(C.Structure):
     """struct ligdiff_dropout"""
     _fields_ = [("seed", C.c_uint64), ("atom_offset", C.c_int64), ("p_attention", C.c_float * 3),
-                ("p_ffn_hidden", C.c_float * 3), ("p_ffn_out", C.c_float * 3)]
+                ("p_ffn_hidden", C.c_float * 3), ("p_ffn_out", C.c_float * 3), ("p_consistency", C.c_float * 2)]
 
 
 class LossArgs(C.Structure):
@@ -98,6 +98,9 @@ SIGNATURES = {
     "ligdiff_consistency": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
+    "ligdiff_consistency_train": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_size_t, C.c_void_p, C.POINTER(Dropout)]),
     "ligdiff_pos_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_float, C.c_float,
                                    C.c_float, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int64, C.c_void_p]),
     "ligdiff_ddim_sample": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,

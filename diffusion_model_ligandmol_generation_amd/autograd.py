@@ -22,13 +22,13 @@ def packed_graph_of(data):
     return g
 
 
-def score_network_apply(model, data, t, properties=None, classifier_free_guidance=False, keep_state=False):
+def score_network_apply(model, data, t, properties=None, classifier_free_guidance=False, keep_state=False,
+                        dropout=None):
     if not hasattr(data, "batch") or data.batch is None:
         batch = torch.zeros(data.x.shape[0], dtype=torch.long, device=data.x.device)   # model1.py:702
         data.batch = batch
     graph = packed_graph_of(data)
     eng = model.engine()
-    dropout = model.dropout_spec(getattr(data, "atom_offset", 0), getattr(data, "dropout_seed", None))
     needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     if needs_grad:
         from .backward import ScoreNetworkFunction

@@ -205,10 +205,22 @@ static void cons_trunk_tail(const float* const* w, int pred, const float* y1, in
   launch_gemm_plain<4>(g, y1, 256, e, 1, s);
 }
 
-extern "C" int ligdiff_consistency(const float* const* w, const ligdiff_graph* g, const float* h, const float* pos,
-                                   const int64_t* pair_ptr, int64_t n_pairs, int32_t n_max, float* atom_logits,
-                                   float* bond_logits, float* valency, float* adjacency, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+// y[row, col] *= mask scale of dropout site d, in place ([rows, 128]): the Dropout between the trunk's
+// second GELU and the last Linear of the atom-type / bond predictor (model1.py:390, :401).
+__global__ void k_dropout_rows128(float* __restrict__ y, int64_t rows, DropSite d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * 128) return;
+  y[i] *= drop_row_scale(d, (int)(i >> 7), (int)(i & 127), 128);
+}
+
+extern "C" int ligdiff_consistency_train(const float* const* w, const ligdiff_graph* g, const float* h, const float* pos,
+                                         const int64_t* pair_ptr, int64_t n_pairs, int32_t n_max, float* atom_logits,
+                                         float* bond_logits, float* valency, float* adjacency, void* workspace,
+                                         size_t workspace_bytes, void* stream, const ligdiff_dropout* dropout) {
+  DropSite d_atom, d_bond;
+  if (!make_drop_site(dropout, 0, LIGDIFF_DROP_CONS_ATOM, &d_atom) || !make_drop_site(dropout, 0, LIGDIFF_DROP_CONS_BOND, &d_bond))
+    return LIGDIFF_ERR_ARG;
+  if (dropout != nullptr && dropout->atom_offset < 0) return LIGDIFF_ERR_ARG;
   if (!w || !g || !h || !pos || !pair_ptr || !atom_logits || !valency || !adjacency || !workspace) return LIGDIFF_ERR_ARG;
   if (n_pairs > 0 && !bond_logits) return LIGDIFF_ERR_ARG;
   {
@@ -236,6 +248,8 @@ extern "C" int ligdiff_consistency(const float* const* w, const ligdiff_graph* g
     e.bias[0] = w[W_CONS(CONS_ATOM, CONS_B0)]; e.gamma[0] = w[W_CONS(CONS_ATOM, CONS_G)]; e.beta[0] = w[W_CONS(CONS_ATOM, CONS_BE)];
     launch_gemm_plain<8>(gc, h, 256, e, 1, s);
     cons_trunk_tail(w, CONS_ATOM, F(L.y1), N, F(L.y2), s);
+    if (d_atom.thr != 0u)
+      hipLaunchKernelGGL(k_dropout_rows128, dim3(ceil_div((long)N * 128, 256)), dim3(256), 0, s, F(L.y2), (int64_t)N, d_atom);
     GemmCore g6 = core_blocks(N, 128, LD_A, w[W_CONS(CONS_ATOM, CONS_WL)], 128, 1, 128);
     EpiBiasAct<4, ACT_NONE, false> e6;
     memset(&e6, 0, sizeof e6);
@@ -278,10 +292,20 @@ extern "C" int ligdiff_consistency(const float* const* w, const ligdiff_graph* g
                          w[W_CONS(CONS_BOND, CONS_B0)], w[W_CONS(CONS_BOND, CONS_G)], w[W_CONS(CONS_BOND, CONS_BE)],
                          g->mol_ptr, pair_ptr, B, n_pairs, F(L.yb1));
       cons_trunk_tail(w, CONS_BOND, F(L.yb1), NP, F(L.yb2), s);
+      if (d_bond.thr != 0u)
+        hipLaunchKernelGGL(k_dropout_rows128, dim3(ceil_div((long)NP * 128, 256)), dim3(256), 0, s, F(L.yb2), (int64_t)NP, d_bond);
       hipLaunchKernelGGL(k_bond_out, dim3(ceil_div(n_pairs, 4)), dim3(256), 0, s, F(L.yb2), w[W_CONS(CONS_BOND, CONS_WL)],
                          w[W_CONS(CONS_BOND, CONS_BL)], g->mol_ptr, pair_ptr, B, n_pairs, n_max, bond_logits, adjacency);
     }
   }
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;
+}
+
+extern "C" int ligdiff_consistency(const float* const* w, const ligdiff_graph* g, const float* h, const float* pos,
+                                   const int64_t* pair_ptr, int64_t n_pairs, int32_t n_max, float* atom_logits,
+                                   float* bond_logits, float* valency, float* adjacency, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  return ligdiff_consistency_train(w, g, h, pos, pair_ptr, n_pairs, n_max, atom_logits, bond_logits, valency, adjacency,
+                                   workspace, workspace_bytes, stream, nullptr);
 }

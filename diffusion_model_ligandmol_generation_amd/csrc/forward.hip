@@ -149,12 +149,14 @@ bool make_drop_site(const ligdiff_dropout* d, int layer, int kind, DropSite* out
   memset(out, 0, sizeof *out);
   if (d == nullptr) return true;
   const float p = kind == LIGDIFF_DROP_ATTENTION ? d->p_attention[layer]
-                  : kind == LIGDIFF_DROP_FFN_HIDDEN ? d->p_ffn_hidden[layer] : d->p_ffn_out[layer];
+                  : kind == LIGDIFF_DROP_FFN_HIDDEN ? d->p_ffn_hidden[layer]
+                  : kind == LIGDIFF_DROP_FFN_OUT ? d->p_ffn_out[layer]
+                  : d->p_consistency[kind - LIGDIFF_DROP_CONS_ATOM];
   if (!(p >= 0.0f && p < 1.0f)) return false;
   if (p == 0.0f) return true;
   out->seed = d->seed;
-  out->row_offset = d->atom_offset;
-  out->site = (uint32_t)(layer * 4 + kind);
+  out->row_offset = kind == LIGDIFF_DROP_CONS_BOND ? 0 : d->atom_offset;   // pairs are numbered per call
+  out->site = kind >= LIGDIFF_DROP_CONS_ATOM ? (uint32_t)(12 + kind) : (uint32_t)(layer * 4 + kind);
   const double t = (double)p * 4294967296.0;
   out->thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
   if (out->thr == 0u) out->thr = 1u;
@@ -171,12 +173,16 @@ int check_dropout(const ligdiff_dropout* d) {
       if (!make_drop_site(d, l, k, &ds)) return LIGDIFF_ERR_ARG;
       any = any || ds.thr != 0u;
     }
+  for (int k = LIGDIFF_DROP_CONS_ATOM; k <= LIGDIFF_DROP_CONS_BOND; ++k) {
+    DropSite ds;
+    if (!make_drop_site(d, 0, k, &ds)) return LIGDIFF_ERR_ARG;
+  }
   if (any && !use_cs()) return LIGDIFF_ERR_ARG;   // only the column-split GEMM epilogues carry the masks
   return LIGDIFF_OK;
 }
 
 __global__ void k_dropout_mask(DropSite d, int kind, int64_t n_atoms, float* __restrict__ out) {
-  const int width = kind == LIGDIFF_DROP_FFN_OUT ? 256 : 1024;
+  const int width = kind >= LIGDIFF_DROP_CONS_ATOM ? 128 : kind == LIGDIFF_DROP_FFN_OUT ? 256 : 1024;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_atoms * width) return;
   const int row = (int)(i / width), col = (int)(i % width);
@@ -193,11 +199,12 @@ __global__ void k_dropout_mask(DropSite d, int kind, int64_t n_atoms, float* __r
 }
 extern "C" int ligdiff_dropout_mask(const ligdiff_dropout* dropout, int32_t layer, int32_t kind, int64_t n_atoms,
                                     float* out, void* stream) {
-  if (!dropout || layer < 0 || layer > 2 || kind < 0 || kind > 2 || n_atoms <= 0 || !out || n_atoms >= (1LL << 30))
+  if (!dropout || layer < 0 || layer > 2 || kind < 0 || kind > LIGDIFF_DROP_CONS_BOND || n_atoms <= 0 || !out ||
+      n_atoms >= (1LL << 30))
     return LIGDIFF_ERR_ARG;
   DropSite ds;
   if (!make_drop_site(dropout, layer, kind, &ds)) return LIGDIFF_ERR_ARG;
-  const int width = kind == LIGDIFF_DROP_FFN_OUT ? 256 : 1024;
+  const int width = kind >= LIGDIFF_DROP_CONS_ATOM ? 128 : kind == LIGDIFF_DROP_FFN_OUT ? 256 : 1024;
   hipLaunchKernelGGL(k_dropout_mask, dim3(ceil_div(n_atoms * width, 256)), dim3(256), 0, (hipStream_t)stream, ds, kind,
                      n_atoms, out);
   LD_CHECK_LAUNCH();

@@ -214,8 +214,9 @@ class ScoreNetworkEngine:
         """The mask scales (0 or 1 / (1 - p)) the library applies at one dropout site for atoms
         [0, n_atoms) of a call made with ``dropout`` (ligdiff_dropout_mask): kind 0 attention
         probabilities [n_atoms, 8, 128] (query atom, head, key index in its molecule), 1 FFN hidden
-        [n_atoms, 1024], 2 FFN output [n_atoms, 256]."""
-        shape = {0: (n_atoms, 8, 128), 1: (n_atoms, 1024), 2: (n_atoms, 256)}[kind]
+        [n_atoms, 1024], 2 FFN output [n_atoms, 256], 3 / 4 the consistency module's atom-type / bond predictor
+        hidden [n_atoms or ordered pairs, 128]."""
+        shape = {0: (n_atoms, 8, 128), 1: (n_atoms, 1024), 2: (n_atoms, 256), 3: (n_atoms, 128), 4: (n_atoms, 128)}[kind]
         out = torch.empty(shape, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             check(self.lib.ligdiff_dropout_mask(C.byref(dropout), int(layer), int(kind), int(n_atoms), _ptr(out), _stream()),
@@ -272,7 +273,7 @@ class ScoreNetworkEngine:
         with torch.cuda.device(self.device):
             check(self.lib.ligdiff_ddim_step(C.byref(args), int(t_cur), int(t_next), _stream()), "ligdiff_ddim_step")
 
-    def consistency(self, graph, ws, flags):
+    def consistency(self, graph, ws, flags, dropout=None):
         """MolDiff consistency outputs (model1.py:750-753) from the state a forward call left in
         its workspace ``ws`` (called with ``flags``).  Returns the reference's 4-tuple
         (atom_logits [N,119], bond_logits [P,5] or None, valency_constrained [N,N],
@@ -293,10 +294,11 @@ class ScoreNetworkEngine:
         adjacency = torch.empty(B, n_max, n_max, 5, dtype=torch.float32, device=dev)
         cws = torch.empty(lib.ligdiff_consistency_workspace_bytes(N, n_pairs), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.ligdiff_consistency(self.table, C.byref(graph.c), ws.data_ptr() + h_off.value,
-                                         ws.data_ptr() + p_off.value, _ptr(pair_ptr), n_pairs, n_max,
-                                         _ptr(atom_logits), _ptr(bond_logits), _ptr(valency), _ptr(adjacency),
-                                         _ptr(cws), cws.numel(), _stream())
+            rc = lib.ligdiff_consistency_train(self.table, C.byref(graph.c), ws.data_ptr() + h_off.value,
+                                               ws.data_ptr() + p_off.value, _ptr(pair_ptr), n_pairs, n_max,
+                                               _ptr(atom_logits), _ptr(bond_logits), _ptr(valency), _ptr(adjacency),
+                                               _ptr(cws), cws.numel(), _stream(),
+                                               C.byref(dropout) if dropout is not None else None)
         check(rc, "ligdiff_consistency")
         self.last_forward = None
         return atom_logits, bond_logits, valency, adjacency

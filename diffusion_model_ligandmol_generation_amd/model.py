@@ -103,6 +103,9 @@ class ResearchAccurateDiffusionModel(nn.Module):
             d.p_ffn_hidden[l] = float(lyr.ff_network[2].p)
             d.p_ffn_out[l] = float(lyr.ff_network[4].p)
             any_p = any_p or d.p_attention[l] > 0 or d.p_ffn_hidden[l] > 0 or d.p_ffn_out[l] > 0
+        cons = self.moldiff_consistency                                  # model1.py:390, :401
+        d.p_consistency[0], d.p_consistency[1] = float(cons.atom_predictor[5].p), float(cons.bond_predictor[5].p)
+        any_p = any_p or d.p_consistency[0] > 0 or d.p_consistency[1] > 0
         if not any_p:
             return None
         d.seed = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item()) if seed is None else int(seed)
@@ -119,7 +122,7 @@ class ResearchAccurateDiffusionModel(nn.Module):
 
         consistency_outputs: None in eval mode; in train mode the MolDiff consistency module's
         (atom_logits, bond_logits, valency_constrained, adjacency_matrix) as model1.py:750-753
-        returns them, computed without dropout and detached (none of them reaches a loss with
+        returns them, with the module's own dropout and detached (none of them reaches a loss with
         the data pipeline's batches: train.py:519, :543, :559, :583).  A true
         ``data.skip_consistency`` (the attribute model1.py:928 attaches) or
         ``model.skip_consistency`` leaves it out: its [N,N] valency output is quadratic in the
@@ -129,14 +132,15 @@ class ResearchAccurateDiffusionModel(nn.Module):
         from .autograd import packed_graph_of, score_network_apply
         want_cons = (self.training and not getattr(self, "skip_consistency", False)
                      and not getattr(data, "skip_consistency", False))
-        atom_pred, pos_pred, prop_pred = score_network_apply(self, data, t, properties,
-                                                             classifier_free_guidance, keep_state=want_cons)
+        dropout = self.dropout_spec(getattr(data, "atom_offset", 0), getattr(data, "dropout_seed", None))
+        atom_pred, pos_pred, prop_pred = score_network_apply(self, data, t, properties, classifier_free_guidance,
+                                                             keep_state=want_cons, dropout=dropout)
         cons = None
         if want_cons:
             eng = self.engine()
             ws, flags = eng.last_forward
             with torch.no_grad():
-                cons = eng.consistency(packed_graph_of(data), ws, flags)
+                cons = eng.consistency(packed_graph_of(data), ws, flags, dropout)
         return atom_pred, pos_pred, prop_pred, cons
 
     def compute_loss(self, data, t, properties=None, loss_weights=None, draws=None):

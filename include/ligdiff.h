@@ -172,9 +172,15 @@ typedef struct ligdiff_dropout {
   float p_attention[3];     /* per attention layer: probabilities, FFN hidden, FFN output         */
   float p_ffn_hidden[3];
   float p_ffn_out[3];
+  float p_consistency[2];   /* consistency module (model1.py:390, :401): Dropout inside the atom-type */
+                            /* and the bond predictor; read by ligdiff_consistency_train only     */
 } ligdiff_dropout;
 
-enum ligdiff_dropout_kind { LIGDIFF_DROP_ATTENTION = 0, LIGDIFF_DROP_FFN_HIDDEN = 1, LIGDIFF_DROP_FFN_OUT = 2 };
+enum ligdiff_dropout_kind {
+  LIGDIFF_DROP_ATTENTION = 0, LIGDIFF_DROP_FFN_HIDDEN = 1, LIGDIFF_DROP_FFN_OUT = 2,
+  LIGDIFF_DROP_CONS_ATOM = 3,   /* layer ignored; [n_atoms, 128], row = atom (global index)        */
+  LIGDIFF_DROP_CONS_BOND = 4    /* layer ignored; [n_pairs, 128], row = ordered pair of THIS call   */
+};
 
 /* ligdiff_forward / ligdiff_backward with dropout (NULL = none: identical to the plain entry points).
  * Needs the default GEMM kernels (no LIGDIFF_GEMM_V1 / LIGDIFF_GEMM_NOCS in the environment). */
@@ -187,7 +193,8 @@ int ligdiff_forward_train(const float* const* weights, const ligdiff_graph* grap
 /* Writes the mask scale (0 or 1 / (1 - p)) of every element of one dropout site for atoms
  * [0, n_atoms) of a call made with `dropout`: kind LIGDIFF_DROP_FFN_HIDDEN -> out [n_atoms, 1024],
  * LIGDIFF_DROP_FFN_OUT -> out [n_atoms, 256], LIGDIFF_DROP_ATTENTION -> out [n_atoms, 8, 128] indexed
- * (query atom, head, key index within the query's molecule). */
+ * (query atom, head, key index within the query's molecule); the two consistency kinds -> out
+ * [n_atoms or n_pairs (passed as n_atoms), 128]. */
 int ligdiff_dropout_mask(const ligdiff_dropout* dropout, int32_t layer, int32_t kind, int64_t n_atoms,
                          float* out, void* stream);
 
@@ -298,12 +305,18 @@ int ligdiff_forward_state_offsets(int64_t n_atoms, int64_t n_edges, int32_t n_mo
  * Outputs: atom_logits [N,119]; bond_logits [n_pairs,5] (may be NULL when n_pairs == 0);
  * valency [N,N] with valency[i,j] = min(valency_pred[j], max_valences[argmax_i]) - the [N] x [N,1]
  * broadcast of model1.py:468; adjacency [n_mols, n_max, n_max, 5]: softmax bond probabilities,
- * [1,0,0,0,0] on the diagonal of real atoms, zeros in the padding.  Dropout is not applied. */
+ * [1,0,0,0,0] on the diagonal of real atoms, zeros in the padding.  No dropout (see ligdiff_consistency_train). */
 size_t ligdiff_consistency_workspace_bytes(int64_t n_atoms, int64_t n_pairs);
 int ligdiff_consistency(const float* const* weights, const ligdiff_graph* graph, const float* h, const float* pos,
                         const int64_t* pair_ptr, int64_t n_pairs, int32_t n_max, float* atom_logits,
                         float* bond_logits, float* valency, float* adjacency, void* workspace,
                         size_t workspace_bytes, void* stream);
+
+/* ligdiff_consistency with the module's train-mode dropout (dropout->p_consistency; NULL = none). */
+int ligdiff_consistency_train(const float* const* weights, const ligdiff_graph* graph, const float* h, const float* pos,
+                              const int64_t* pair_ptr, int64_t n_pairs, int32_t n_max, float* atom_logits,
+                              float* bond_logits, float* valency, float* adjacency, void* workspace,
+                              size_t workspace_bytes, void* stream, const ligdiff_dropout* dropout);
 
 /* Measurement hook (no counterpart in the reference): runs `reps` forwards and returns in
  * *mean_ms_host (host pointer) the mean duration, from HIP events recorded on `stream`, of

@@ -65,4 +65,6 @@ def no_dropout(model):
         lyr.attention.dropout = 0.0
         lyr.ff_network[2].p = 0.0
         lyr.ff_network[4].p = 0.0
+    model.moldiff_consistency.atom_predictor[5].p = 0.0       # tests/golden/make_golden_alt.py does the same
+    model.moldiff_consistency.bond_predictor[5].p = 0.0
     return model

@@ -177,3 +177,34 @@ def test_dropout_is_bitwise_independent_of_sharding(split):
         lib.ligdiff_set_split_gemm(prev)
     assert torch.equal(torch.cat([q[0] for q in parts]), a) and torch.equal(torch.cat([q[1] for q in parts]), p)
     assert not torch.equal(a, b)
+
+
+def test_consistency_module_dropout_matches_oracle_under_exported_masks():
+    """Train-mode fourth output of the model with the consistency module's own Dropout(0.1) active
+    (model1.py:390, :401): the library's masks, exported, applied by the oracle."""
+    sizes = [29, 3, 17, 40, 2]
+    t = _batch(sizes, seed=8)
+    N = t["x"].shape[0]
+    model = copy.deepcopy(seed0_model()).cuda().train()
+    for lyr in model.dit_layers:            # isolate the consistency module's dropout
+        lyr.attention.dropout = 0.0
+        lyr.ff_network[2].p = 0.0
+        lyr.ff_network[4].p = 0.0
+    sd = seed0_state_dict()
+    tt = torch.tensor([3.0, 999.0, 500.0, 250.0, 0.0])
+    d = Bag(x=t["x"].cuda(), pos=t["pos"].cuda(), edge_index=t["edge_index"].cuda(), batch=t["batch"].cuda(),
+            dropout_seed=77, atom_offset=0)
+    with torch.no_grad():
+        got = model(d, tt.cuda())[3]
+        spec = model.dropout_spec(0, 77)
+        eng = model.engine()
+        n_pairs = sum(n * (n - 1) for n in sizes)
+        masks = {"atom": eng.dropout_mask(spec, 0, 3, N).cpu(), "bond": eng.dropout_mask(spec, 0, 4, n_pairs).cpu()}
+        assert abs(float((masks["bond"] != 0).float().mean()) - 0.9) < 5e-3
+        _, _, _, inter = oracle.score_network_forward(sd, t["x"], t["pos"], t["edge_index"], t["batch"], tt, None,
+                                                      pad_to_max_atoms=False, return_intermediates=True)
+        want = oracle.consistency_forward(sd, inter["h_dit"], t["pos"] + inter["pos_updates"], t["batch"], dropout=masks)
+        plain = oracle.consistency_forward(sd, inter["h_dit"], t["pos"] + inter["pos_updates"], t["batch"])
+    for g_, w_ in zip(got, want):
+        torch.testing.assert_close(g_.cpu(), w_, rtol=1e-4, atol=2e-5)
+    assert float((got[0].cpu() - plain[0]).abs().max()) > 50 * float((got[0].cpu() - want[0]).abs().max())
