@@ -501,6 +501,12 @@ def run_rank(args):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["cpu_baseline_batched"] = cpu_baseline_batched()
+            try:   # BASELINE configs[0]: the main.py flow at batch 64 (1 train step + 100-step DDPM), oracle beside it
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import run_config1
+                out["config1"] = run_config1.run(device=dev)
+            except Exception as e:   # noqa: BLE001
+                out["config1"] = {"error": repr(e)}
 
     # ---- the other named workloads.  The headline above is final; a watchdog prints it alone if the legs
     # below do not come back in time (e.g. one rank stuck in a collective), so that it cannot be lost.
