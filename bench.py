@@ -308,7 +308,10 @@ def leg_config4_fc_sampling(ctx, mols_per_rank=48, traffic=None):
            "molecules": len(sizes), "molecules_rank0": len(mine), "atoms_rank0": graph.n_atoms,
            "edges_rank0": graph.n_edges, "ddpm_steps": T_STEPS, "seconds": dt,
            "molecules_per_s": len(sizes) / dt, "ms_per_reverse_step": dt / T_STEPS * 1e3,
-           "finite": bool(torch.isfinite(x).all() and torch.isfinite(pos).all())}
+           "finite": bool(torch.isfinite(x).all() and torch.isfinite(pos).all()),
+           "note": "with random-init weights a fully connected ligand of this size leaves the finite range after a few "
+                   "dozen reverse steps (each atom's coordinate update sums over n - 1 neighbours); the CPU oracle does "
+                   "the same step for step (tests/test_gpu_full_edges.py), and the work per step does not depend on the values"}
     if ctx.rank == 0:      # dominant kernel at this shape: the second edge-MLP GEMM ([E,256] x [256,256] + LayerNorm)
         t_index = torch.full((1,), 500, dtype=torch.int32, device=dev)
         g2, _ = full_graph(mine, dev)

@@ -188,3 +188,44 @@ def test_consecutive_generate_calls_draw_fresh_noise():
     assert gen.seed == 79 and not np.array_equal(c1[0][0], c2[0][0])
     d1, _ = gen.sample_many(sizes, None, 1.0, 1.0, seed=77)
     assert np.array_equal(c1[0][0], d1[0][0])
+
+
+def test_fully_connected_free_running_growth_matches_oracle():
+    """With random-init weights a fully connected large ligand leaves the finite range within a few
+    dozen reverse steps (the coordinate update sums over n - 1 neighbours per atom and feeds back).
+    That is the model, not the kernels: the free-running HIP trajectory follows the oracle's through
+    the growth, step for step, until both stop being finite."""
+    class Stop(Exception):
+        pass
+
+    T, n, last = 1000, 65, 975
+    gen = _gen(T)
+    sd = seed0_state_dict(timesteps=T, max_atoms=128)
+    sched = oracle.cosine_schedule(T)
+    noise = BatchNoise(11)
+    snaps = {}
+
+    def trace(t, a, b):
+        snaps[t] = (a.cpu().clone(), b.cpu().clone())
+        if t == last:
+            raise Stop()
+
+    with pytest.raises(Stop):
+        gen.sample_batch([n], None, 1.0, 1.0, noise=noise, connectivity="full", trace=trace)
+    ei = torch.tensor(oracle.fully_connected_edges(n), dtype=torch.long).t().contiguous()
+    osnaps = {}
+
+    def otrace(t, a, b):
+        osnaps[t] = (a.clone(), b.clone())
+        if t == last:
+            raise Stop()
+
+    order = iter([noise.d[("x0", T)], noise.d[("pos0", T)]] + [noise.d[(k, t)] for t in range(T - 1, last, -1) for k in ("x", "pos")])
+    with pytest.raises(Stop), torch.no_grad():
+        oracle.ddpm_sample(sd, sched, n, lambda shape: next(order), max_atoms=128, pad=False, edge_index=ei, trace=otrace)
+    grew = float(osnaps[last][1].abs().max()) / float(osnaps[T - 1][1].abs().max())
+    assert grew > 3.0                                  # coordinates are running away already
+    for t in range(T - 1, last - 1, -1):
+        for got, want in zip(snaps[t], osnaps[t]):
+            assert torch.isfinite(want).all()
+            assert float((got - want).abs().max()) <= 1e-3 * float(want.abs().max()), t
