@@ -72,18 +72,21 @@ def profile_traffic():
     process; a kernel that the summary does not list gets None."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
     files = [f for f in files if "split" not in os.path.basename(f)]
-    if not files:
-        return {}, None
-    path = files[-1]
-    vals = {}
-    with open(path) as fh:
-        for row in csv.DictReader(fh):
-            vals.setdefault(row["Kernel_Name"], {})[row["Counter_Name"]] = float(row["Mean_Counter_Value_KB"])
-    out = {}
-    for name, c in vals.items():
-        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            out[name] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-    return out, os.path.relpath(path, ROOT)
+    fwd = [f for f in files if "train" not in os.path.basename(f)]
+    trn = [f for f in files if "train" in os.path.basename(f)]
+    out, used = {}, []
+    # the training-step passes first, then the forward passes on top: a kernel that both list
+    # takes the forward-only figure (the sampling shape)
+    for path in ([trn[-1]] if trn else []) + ([fwd[-1]] if fwd else []):
+        vals = {}
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                vals.setdefault(row["Kernel_Name"], {})[row["Counter_Name"]] = float(row["Mean_Counter_Value_KB"])
+        for name, c in vals.items():
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                out[name] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        used.append(os.path.relpath(path, ROOT))
+    return out, (" + ".join(used) if used else None)
 
 
 def traffic_of(table, *needles):
@@ -454,14 +457,14 @@ def run_rank(args):
                 return {"kernel": "gemm_cs_kernel<APtrPlain, EpiBiasAct<8,GELU>> (dit*.ffn_up, M=29696 K=256 N=1024)",
                         "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                        "traffic": traffic_of(traffic, "gemm_cs_kernel<", "EpiBiasAct<8, 1, false>"),
+                        "traffic": traffic_of(traffic, "gemm_cs_kernel<", "EpiBiasAct<8, 1, false, false>"),
                         "traffic_source": traffic_src, "avg_launch_ms": ms}
             # six bf16 x bf16 products per fp32 product: the matrix pipe executes 6x the algorithmic flops
             ach = 6.0 * flops / (ms * 1e-3) / 1e12
             return {"kernel": "gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8,GELU>> (dit*.ffn_up, M=29696 K=256 N=1024)",
                     "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-                    "traffic": traffic_of(traffic, "gemm_cs_split_kernel<", "EpiBiasAct<8, 1, false>"),
+                    "traffic": traffic_of(traffic, "gemm_cs_split_kernel<", "EpiBiasAct<8, 1, false, false>"),
                     "traffic_source": traffic_src, "avg_launch_ms": ms,
                     "fp32_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
                     "note": "achieved counts the six bf16 MFMA products issued per fp32 product"}
