@@ -6,6 +6,8 @@
 
 #include "epilogues.h"
 #include "gemm3.h"
+#include "ffn_chain.h"
+#include "edge_chain.h"
 #include "forward.h"
 #include "kernels.h"
 #include "weights.h"
@@ -416,6 +418,8 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
 
   // --- E(3) message-passing layers (model1.py:721-725, :86-114)
   const float* h_in = F(L.h0);
+  // inference on the fp32 pipe: the three edge launches of a layer run as one fused kernel
+  const bool edge_chain = use_chain() && !L.save && g_split == nullptr && E > 0 && (int64_t)N * 512 < (1LL << 31);
   for (int l = 0; l < 3; ++l) {
     const float* pos_l = (l == 0) ? pos : F(L.pos_cur);
     // per-node halves of the first edge linear: P = h [W1a | W1b]^T
@@ -436,6 +440,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         EpiBiasAct<8, ACT_NONE, false> e2;
         memset(&e2, 0, sizeof e2);
         e2.M = N; e2.n_valid = 256; e2.col_block = 256; e2.C = F(L.P[l]); e2.ldc = 512; e2.alpha = 1.0f;
+        if (edge_chain) e2.bias[1] = w[W_E3(l, E3_EN0_B)];   // the fused edge kernel expects b1 inside Pb
         launch_gemm_cs(g2, APtrPlain{h_in, 256}, e2, 2, s);
       } else {
         launch_gemm_plain<4>(gc, h_in, 256, e, 4, s);
@@ -448,6 +453,18 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
                          w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB0_B)], w[W_E3(l, E3_RB2_W)], w[W_E3(l, E3_RB2_B)],
                          F(L.rel[l]), F(L.rbf[l]), S(L.dist[l]), S(L.r1pre[l]), E);
       PE();
+      if (edge_chain) {
+        EdgeChainArgs ea;
+        memset(&ea, 0, sizeof ea);
+        ea.E = E; ea.rbf = F(L.rbf[l]); ea.rel = F(L.rel[l]); ea.src = g->src; ea.dst = g->dst; ea.P = F(L.P[l]);
+        ea.Wc = w[W_E3(l, E3_EN0_W)] + 512; ea.ldwc = 544;
+        ea.W2 = w[W_E3(l, E3_EN2_W)]; ea.b2 = w[W_E3(l, E3_EN2_B)]; ea.gamma = w[W_E3(l, E3_EN3_G)]; ea.beta = w[W_E3(l, E3_EN3_B)];
+        ea.Wc1 = w[W_E3(l, E3_CN0_W)]; ea.bc1 = w[W_E3(l, E3_CN0_B)]; ea.wc2 = w[W_E3(l, E3_CN2_W)]; ea.bc2 = w[W_E3(l, E3_CN2_B)];
+        ea.msg = F(L.msg[l]); ea.wrel = F(L.wrel[l]);
+        PB("e3_%d.edge_chain", l);
+        hipLaunchKernelGGL((edge_chain_kernel<false, 0>), dim3(ceil_div(E, 128)), dim3(256), 0, s, ea);
+        PE();
+      } else {
       {  // a1 = SiLU(Pa[src] + Pb[dst] + Wc rbf + b1)
         GemmCore gc;
         memset(&gc, 0, sizeof gc);
@@ -481,6 +498,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
           launch_gemm<4, W_ALIGNED>(gc, alc, e, 1, s);
         }
         PE();
+      }
       }
     }
     PB("e3_%d.aggregate", l);
@@ -581,6 +599,26 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     if (!make_drop_site(drop, l, LIGDIFF_DROP_FFN_HIDDEN, &dh) || !make_drop_site(drop, l, LIGDIFF_DROP_FFN_OUT, &dout))
       return LIGDIFF_ERR_ARG;
     if ((dh.thr != 0u || dout.thr != 0u) && !use_cs()) return LIGDIFF_ERR_ARG;
+    // inference on the fp32 pipe: the whole feed-forward block as one launch (the [N,1024] hidden
+    // activations stay in registers); the next layer's pre-norm is fused as in the two-launch form
+    const bool chain = use_chain() && !L.save && dh.thr == 0u && dout.thr == 0u && g_split == nullptr && N > 0;
+    if (chain) {
+      FfnChainArgs fa;
+      memset(&fa, 0, sizeof fa);
+      fa.M = N; fa.XN = F(L.xn2[l]); fa.W1 = w[W_DIT(l, DIT_FF0_W)]; fa.b1 = w[W_DIT(l, DIT_FF0_B)];
+      fa.W2 = w[W_DIT(l, DIT_FF3_W)]; fa.b2 = w[W_DIT(l, DIT_FF3_B)]; fa.resid = F(L.x1[l]);
+      fa.mod = F(L.mod[l]); fa.mod_stride = mstride; fa.gate_off = 1280;
+      fa.mod2 = F(L.mod[l < 2 ? l + 1 : l]); fa.shift_off = 0; fa.scale_off = 256;
+      fa.atom_mol = g->atom_mol; fa.X = F(L.x2[l]); fa.XNout = l < 2 ? F(L.xn1[l + 1]) : F(L.x2[l]);
+      PB("dit%d.ffn", l);
+      if (l < 2)
+        hipLaunchKernelGGL((ffn_chain_kernel<true>), dim3(ceil_div(N, 128)), dim3(256), 0, s, fa);
+      else
+        hipLaunchKernelGGL((ffn_chain_kernel<false>), dim3(ceil_div(N, 128)), dim3(256), 0, s, fa);
+      PE();
+      x_in = F(L.x2[l]);
+      continue;
+    }
     PB("dit%d.ffn_up", l);
     if (dh.thr != 0u) {   // ffh = Dropout(GELU(xn2 W0^T + b)), model1.py:268-270
       GemmCore gc = core_blocks(N, 256, 256, w[W_DIT(l, DIT_FF0_W)], 256, 4, 256);

@@ -26,6 +26,11 @@ static inline bool use_cs() {
   static const bool v = getenv("LIGDIFF_GEMM_NOCS") == nullptr && getenv("LIGDIFF_GEMM_V1") == nullptr;
   return v;
 }
+// Fused chain kernels (ffn_chain.h) on the inference path unless LIGDIFF_NO_CHAIN is set (A/B switch).
+static inline bool use_chain() {
+  static const bool v = use_cs() && getenv("LIGDIFF_NO_CHAIN") == nullptr;
+  return v;
+}
 // Split-operand mode (gemm4.h): while a cache is installed for the calling thread, the column-split
 // launches below convert each weight block they meet for the first time (one small launch on the
 // same stream) and run the bf16-pipe kernel; without a cache, or once its region is full, they run
