@@ -1,0 +1,318 @@
+// Fused attention-layer tail (inference form), model1.py:295-300 (+ :293 of the next layer):
+//   x1  = x + gate_msa * (att Wo^T + bo)
+//   xn2 = LN(x1; eps 1e-6, no affine) (1 + scale_mlp) + shift_mlp
+//   x2  = x1 + gate_mlp * (GELU(xn2 W1^T + b1) W2^T + b2)                       -> HBM (residual stream)
+//   TAIL_QKV:  qkv' = (LN(x2) (1 + scale_msa') + shift_msa') Wqkv'^T + bqkv'   -> HBM (the NEXT layer's attention input)
+// i.e. everything between two attention kernels as ONE launch; x1 makes one round trip through HBM
+// (written behind the first feed-forward step, read back behind the last), the [M,1024] hidden
+// activations, xn2 and the next layer's pre-norm never leave the registers (layout: chain.h).
+//
+// One workgroup = 4 waves = 128 atoms.  Weight tiles go through a ring of four 32-KiB LDS buffers, tile
+// s in buffer s & 3, fetched two steps ahead behind the MFMAs of step s - 2:
+//   s = 0..7          WIDE tiles of Wo          (out-projection, one output tile each)
+//   s = 8 + 2t, 9 + 2t  WIDE tile t of W1, TALL tile t of W2   (t = 0..31)
+//   s = 72 + q        WIDE tiles of Wqkv'       (q = 0..23, TAIL_QKV)
+// The small vectors (adaLN rows when all molecules share the timestep, biases) are staged in LDS once.
+#pragma once
+#include "chain.h"
+
+struct DitChainArgs {
+  int M;
+  const float* att;     // [M,256] attention output (heads concatenated)
+  const float* x;       // [M,256] residual stream in
+  float* xout;          // [M,256] residual stream out (may be x)
+  const float* Wo; const float* bo;
+  const float* W1; const float* b1; const float* W2; const float* b2;
+  const float* mod; int mod_stride;   // this layer's adaLN rows [B or 1, stride]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
+  const float* mod_next;              // the next layer's rows (TAIL_QKV): shift_msa | scale_msa | ...
+  const int32_t* atom_mol;
+  const float* Wqkv; const float* bqkv; float* qkv;   // TAIL_QKV: next layer's in_proj, output [M,768]
+  unsigned long long* stamps;   // diagnostic builds (DBG): [grid][8] shader-clock stamps of wave 0
+};
+
+// GELU (erf form) of an accumulator tile, two elements per packed instruction: with t = |x| and
+// p = sum_k c_k t^k (c_k = a_k 2^(-k/2) 2^(1/16), a_k of Abramowitz-Stegun 7.1.28),
+//   GELU(x) = max(x, 0) - |x| / (2 (1 + a1 t/sqrt2 + ...)^16) = max(x, 0) - |x| p^-16.   |error| <= 8e-7
+__device__ __forceinline__ void gelu_tile(f32x16& u) {
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    const f32x2 x = {u[k], u[k + 1]};
+    const f32x2 t = __builtin_elementwise_abs(x);
+    f32x2 p = t * 5.62129980608006e-06f + 5.105520904180594e-05f;
+    p = p * t + 3.9686136005911976e-05f;
+    p = p * t + 0.003422739217057824f;
+    p = p * t + 0.02207699790596962f;
+    p = p * t + 0.052075162529945374f;
+    p = p * t + 1.0442737340927124f;
+    p = p * p; p = p * p; p = p * p; p = p * p;
+    const f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+    const f32x2 tr = t * r;
+    u[k] = fmaxf(x[0], 0.f) - tr[0];
+    u[k + 1] = fmaxf(x[1], 0.f) - tr[1];
+  }
+}
+
+#define DC_VEC_MOD 0        // 1536 floats: this layer's adaLN rows (shared-timestep form)
+#define DC_VEC_MODN 1536    // 512: next layer's shift_msa | scale_msa
+#define DC_VEC_BO 2048
+#define DC_VEC_B2 2304
+#define DC_VEC_B1 2560      // 1024
+#define DC_VEC_BQKV 3584    // 768
+#define DC_VEC_FL 4352
+
+template <bool SHARED, bool TAIL_QKV, bool DBG = false>   // SHARED: mod_stride == 0 (one adaLN row set for all molecules)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void dit_chain_kernel(DitChainArgs p) {
+  __shared__ __attribute__((aligned(1024))) float smem[4 * CH_TILE_FL + DC_VEC_FL];
+  float* const vec = smem + 4 * CH_TILE_FL;
+  const int tid = threadIdx.x;
+  ChainLane cl;
+  cl.init(smem, tid);
+  const int fi = cl.fi, h = cl.h;
+  const int row = blockIdx.x * 128 + cl.wave * 32 + fi;
+  const int rr = row < p.M ? row : p.M - 1;
+  auto stamp = [&](int k) {
+    if (DBG && tid == 0) p.stamps[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+
+  // piece n of ring tile s (uniform s)
+  auto fetch = [&](int s, int n) {
+    float* buf = smem + (s & 3) * CH_TILE_FL;
+    if (s < 8) cl.dma_wide(p.Wo, 256, 32 * s, 256, 0, buf, n);
+    else if (s < 72) {
+      const int t = (s - 8) >> 1;
+      if (s & 1) cl.dma_tall(p.W2, 1024, 32 * t, buf, n);
+      else cl.dma_wide(p.W1, 256, 32 * t, 1024, 0, buf, n);
+    } else if (TAIL_QKV) cl.dma_wide(p.Wqkv, 256, 32 * (s - 72), 768, 0, buf, n);
+  };
+  constexpr int S_END = TAIL_QKV ? 96 : 72;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) { fetch(0, n); fetch(1, n); }
+
+  // small vectors -> LDS
+  auto stage = [&](const float* src, int off, int nfl) {
+    for (int i = tid * 4; i < nfl; i += 1024) *reinterpret_cast<f32x4*>(vec + off + i) = *reinterpret_cast<const f32x4*>(src + i);
+  };
+  if (SHARED) {
+    stage(p.mod, DC_VEC_MOD, 1536);
+    if (TAIL_QKV) stage(p.mod_next, DC_VEC_MODN, 512);
+  }
+  stage(p.bo, DC_VEC_BO, 256); stage(p.b2, DC_VEC_B2, 256); stage(p.b1, DC_VEC_B1, 1024);
+  if (TAIL_QKV) stage(p.bqkv, DC_VEC_BQKV, 768);
+
+  // adaLN vector `off` (0 shift_msa .. 1280 gate_mlp), features 8m + 4h .. + 3, for this lane's molecule
+  const float* const mrow = SHARED ? nullptr : p.mod + (size_t)p.atom_mol[rr] * p.mod_stride + 4 * h;
+  const float* const mrow_n = (SHARED || !TAIL_QKV) ? nullptr : p.mod_next + (size_t)p.atom_mol[rr] * p.mod_stride + 4 * h;
+  auto modv = [&](int off, int m) -> f32x4 {
+    if (SHARED) return *reinterpret_cast<const f32x4*>(vec + DC_VEC_MOD + off + 8 * m + 4 * h);
+    return *reinterpret_cast<const f32x4*>(mrow + off + 8 * m);
+  };
+  auto modv_next = [&](int off, int m) -> f32x4 {
+    if (SHARED) return *reinterpret_cast<const f32x4*>(vec + DC_VEC_MODN + off + 8 * m + 4 * h);
+    return *reinterpret_cast<const f32x4*>(mrow_n + off + 8 * m);
+  };
+  auto vec4 = [&](int off, int m) -> f32x4 { return *reinterpret_cast<const f32x4*>(vec + off + 8 * m + 4 * h); };
+
+  unsigned at[4][4], aw[4][8];
+#pragma unroll
+  for (int bf = 0; bf < 4; ++bf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) at[bf][g] = cl.a_tall[g] + bf * CH_TILE_FL * 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) aw[bf][k] = cl.a_wide[k] + bf * CH_TILE_FL * 4;
+  }
+  // every step opens with: all of this wave's memory operations done (the tile fetched during the
+  // previous step among them), then the workgroup barrier (everybody is done with the buffer that this
+  // step's fetch refills, and everybody's pieces of this step's tile have landed one step earlier)
+  auto open_step = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  // one WIDE step: acc += tile(buffer BF) . slab, slab group m = xs[m >> 2] registers 4 (m & 3) ..;  the
+  // fetch of tile s + 2 rides behind groups 8..15, extra(J) behind every group
+  auto wide_step = [&](auto BF, int s, f32x16& acc, f32x16 (&xs)[8], auto&& extra) {
+    constexpr int bf = decltype(BF)::value;
+    chain_groups<32>(
+        [&](auto J) { constexpr int j = decltype(J)::value; return lds_read128<(j >> 3) * 256>(aw[bf][j & 7]); },
+        [&](auto J) {
+          constexpr int m = decltype(J)::value;
+          return f32x4{xs[m >> 2][4 * (m & 3)], xs[m >> 2][4 * (m & 3) + 1], xs[m >> 2][4 * (m & 3) + 2], xs[m >> 2][4 * (m & 3) + 3]};
+        },
+        [&](auto) -> f32x16& { return acc; },
+        [&](auto J) {
+          constexpr int j = decltype(J)::value;
+          if (j >= 8 && j < 16 && s + 2 < S_END) fetch(s + 2, j - 8);
+          extra(J);
+        });
+  };
+  auto tall_step = [&](auto BF, int s, f32x16 (&out)[8], f32x16& u, auto&& extra) {
+    constexpr int bf = decltype(BF)::value;
+    chain_groups<32>(
+        [&](auto J) { constexpr int j = decltype(J)::value; return lds_read128<(j >> 2) * 4096>(at[bf][j & 3]); },
+        [&](auto J) { constexpr int g = decltype(J)::value & 3; return f32x4{u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]}; },
+        [&](auto J) -> f32x16& { return out[decltype(J)::value >> 2]; },
+        [&](auto J) {
+          constexpr int j = decltype(J)::value;
+          if (j >= 8 && j < 16 && s + 2 < S_END) fetch(s + 2, j - 8);
+          extra(J);
+        });
+  };
+  auto init_tile = [&](f32x16& a, int off, int tile) {   // accumulator tile <- bias vector (LDS)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b = vec4(off, tile * 4 + g);
+      a[4 * g] = b[0]; a[4 * g + 1] = b[1]; a[4 * g + 2] = b[2]; a[4 * g + 3] = b[3];
+    }
+  };
+  // LN(v; eps 1e-6, no affine) (1 + scale) + shift over the 256 features of the lane's row
+  auto ln_mod = [&](f32x16 (&v)[8], f32x16 (&y)[8], auto&& scale4, auto&& shift4) {
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += v[o][r];
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / 256.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float d = v[o][r] - mean; q += d * d; }
+    q += __shfl_xor(q, 32);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-6f);
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 sc = scale4(o * 4 + g), sh = shift4(o * 4 + g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[o][4 * g + k] = ((v[o][4 * g + k] - mean) * rstd) * (1.0f + sc[k]) + sh[k];
+      }
+  };
+
+  // ---- out-projection: att slab -> x1
+  f32x16 xs[8];   // the current B slab: att, then xn2, then the next layer's pre-norm
+  {
+    const float* arow = p.att + (size_t)rr * 256 + 4 * h;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 8 * m);
+      xs[m >> 2][4 * (m & 3)] = a[0]; xs[m >> 2][4 * (m & 3) + 1] = a[1]; xs[m >> 2][4 * (m & 3) + 2] = a[2]; xs[m >> 2][4 * (m & 3) + 3] = a[3];
+    }
+  }
+  open_step();   // ring tiles 0, 1 and the small vectors are in LDS
+  stamp(1);
+  f32x16 x1[8];
+  static_for<0, 8>([&](auto O) {
+    constexpr int o = decltype(O)::value;
+    if (o > 0) open_step();
+    init_tile(x1[o], DC_VEC_BO, o);
+    wide_step(std::integral_constant<int, o & 3>{}, o, x1[o], xs, NoHook{});
+  });
+  stamp(2);
+  float* const xrow_out = p.xout + (size_t)rr * 256 + 4 * h;
+  {
+    const float* xrow = p.x + (size_t)rr * 256 + 4 * h;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      const f32x4 rs = *reinterpret_cast<const f32x4*>(xrow + 8 * m);
+      const f32x4 gt = modv(512, m);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x1[m >> 2][4 * (m & 3) + k] = rs[k] + gt[k] * x1[m >> 2][4 * (m & 3) + k];
+    }
+    ln_mod(x1, xs, [&](int m) { return modv(1024, m); }, [&](int m) { return modv(768, m); });
+  }
+
+  stamp(3);
+  // ---- feed-forward: ring steps 8 .. 71, two hidden tiles per trip (static buffer indices)
+  f32x16 out[8];
+  auto store_x1 = [&](auto J) {   // behind the first feed-forward step: x1 -> HBM, one 16-byte piece per group
+    constexpr int j = decltype(J)::value;
+    if (row < p.M)
+      *reinterpret_cast<f32x4*>(xrow_out + 8 * j) =
+          f32x4{x1[j >> 2][4 * (j & 3)], x1[j >> 2][4 * (j & 3) + 1], x1[j >> 2][4 * (j & 3) + 2], x1[j >> 2][4 * (j & 3) + 3]};
+  };
+  auto load_x1 = [&](auto J) {    // behind the last one: back into the same registers
+    constexpr int j = decltype(J)::value;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xrow_out + 8 * j);
+    x1[j >> 2][4 * (j & 3)] = v[0]; x1[j >> 2][4 * (j & 3) + 1] = v[1]; x1[j >> 2][4 * (j & 3) + 2] = v[2]; x1[j >> 2][4 * (j & 3) + 3] = v[3];
+  };
+  auto ffn_pair = [&](int t, auto FIRST, auto LAST) {   // hidden tiles t (buffers 0, 1) and t + 1 (buffers 2, 3)
+    constexpr bool first = decltype(FIRST)::value, last = decltype(LAST)::value;
+    f32x16 u;
+    open_step();
+    init_tile(u, DC_VEC_B1, t);
+    if (first) wide_step(std::integral_constant<int, 0>{}, 8 + 2 * t, u, xs, store_x1);
+    else wide_step(std::integral_constant<int, 0>{}, 8 + 2 * t, u, xs, NoHook{});
+    gelu_tile(u);
+    if (first) {   // (x1's registers are free from here on)
+#pragma unroll
+      for (int o = 0; o < 8; ++o) init_tile(out[o], DC_VEC_B2, o);
+    }
+    open_step();
+    tall_step(std::integral_constant<int, 1>{}, 9 + 2 * t, out, u, NoHook{});
+    open_step();
+    init_tile(u, DC_VEC_B1, t + 1);
+    wide_step(std::integral_constant<int, 2>{}, 10 + 2 * t, u, xs, NoHook{});
+    gelu_tile(u);
+    open_step();
+    if (last) tall_step(std::integral_constant<int, 3>{}, 11 + 2 * t, out, u, load_x1);
+    else tall_step(std::integral_constant<int, 3>{}, 11 + 2 * t, out, u, NoHook{});
+  };
+  ffn_pair(0, std::true_type{}, std::false_type{});
+#pragma unroll 1
+  for (int t = 2; t < 30; t += 2) ffn_pair(t, std::false_type{}, std::false_type{});
+  ffn_pair(30, std::false_type{}, std::true_type{});
+
+  stamp(4);
+  // ---- x2 = x1 + gate_mlp * out
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    const f32x4 gt = modv(1280, m);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x1[m >> 2][4 * (m & 3) + k] += gt[k] * out[m >> 2][4 * (m & 3) + k];
+  }
+  auto store_x2 = [&](auto J) {
+    constexpr int j = decltype(J)::value;
+    if (row < p.M)
+      *reinterpret_cast<f32x4*>(xrow_out + 8 * j) =
+          f32x4{x1[j >> 2][4 * (j & 3)], x1[j >> 2][4 * (j & 3) + 1], x1[j >> 2][4 * (j & 3) + 2], x1[j >> 2][4 * (j & 3) + 3]};
+  };
+  if (!TAIL_QKV) {
+    static_for<0, 32>(store_x2);
+    return;
+  }
+
+  // ---- the next layer's pre-norm and in-projection: ring steps 72 .. 95, four output tiles per trip
+  ln_mod(x1, xs, [&](int m) { return modv_next(256, m); }, [&](int m) { return modv_next(0, m); });
+  stamp(5);
+  float* const qrow = p.qkv + (size_t)rr * 768 + 4 * h;
+  f32x16 qa, qb;
+  auto store_q = [&](f32x16& a, int tile, auto J) {   // 4 pieces of output tile `tile`, behind groups 0..3
+    constexpr int j = decltype(J)::value;
+    if (j < 4 && row < p.M)
+      *reinterpret_cast<f32x4*>(qrow + 32 * tile + 8 * j) = f32x4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
+  };
+  auto qkv_quad = [&](int q, auto FIRST) {
+    constexpr bool first = decltype(FIRST)::value;
+    open_step();
+    init_tile(qa, DC_VEC_BQKV, q);
+    if (first) wide_step(std::integral_constant<int, 0>{}, 72 + q, qa, xs, store_x2);
+    else wide_step(std::integral_constant<int, 0>{}, 72 + q, qa, xs, [&](auto J) { store_q(qb, q - 1, J); });
+    open_step();
+    init_tile(qb, DC_VEC_BQKV, q + 1);
+    wide_step(std::integral_constant<int, 1>{}, 73 + q, qb, xs, [&](auto J) { store_q(qa, q, J); });
+    open_step();
+    init_tile(qa, DC_VEC_BQKV, q + 2);
+    wide_step(std::integral_constant<int, 2>{}, 74 + q, qa, xs, [&](auto J) { store_q(qb, q + 1, J); });
+    open_step();
+    init_tile(qb, DC_VEC_BQKV, q + 3);
+    wide_step(std::integral_constant<int, 3>{}, 75 + q, qb, xs, [&](auto J) { store_q(qa, q + 2, J); });
+  };
+  qkv_quad(0, std::true_type{});
+#pragma unroll 1
+  for (int q = 4; q < 24; q += 4) qkv_quad(q, std::false_type{});
+  static_for<0, 4>([&](auto J) { store_q(qb, 23, J); });
+  stamp(6);
+}

@@ -8,6 +8,8 @@
 #include "gemm3.h"
 #include "ffn_chain.h"
 #include "edge_chain.h"
+#include "dit_chain.h"
+#include "node_chain.h"
 #include "forward.h"
 #include "kernels.h"
 #include "weights.h"
@@ -420,10 +422,15 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   const float* h_in = F(L.h0);
   // inference on the fp32 pipe: the three edge launches of a layer run as one fused kernel
   const bool edge_chain = use_chain() && !L.save && g_split == nullptr && E > 0 && (int64_t)N * 512 < (1LL << 31);
+  // likewise the node update of a layer together with what follows it (the next layer's per-node edge
+  // projections, or the first attention layer's pre-norm and in-projection), and everything between two
+  // attention kernels (out-projection, feed-forward block, the next layer's pre-norm and in-projection)
+  const bool node_chain = use_chain() && !L.save && g_split == nullptr && N > 0;
+  const bool dit_chain = node_chain && drop == nullptr;
   for (int l = 0; l < 3; ++l) {
     const float* pos_l = (l == 0) ? pos : F(L.pos_cur);
     // per-node halves of the first edge linear: P = h [W1a | W1b]^T
-    {
+    if (!node_chain || l == 0) {
       GemmCore gc;
       memset(&gc, 0, sizeof gc);
       gc.M = N; gc.K = 256; gc.n_valid = 128; gc.ldw = 544;
@@ -506,6 +513,29 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
                        g->src_ptr, g->src_slot, pos, F(L.pos_upd), F(L.pos_cur), F(L.agg[l]), (float*)nullptr, N,
                        l == 0 ? 1 : 0);
     PE();
+    if (node_chain) {
+      NodeChainArgs na;
+      memset(&na, 0, sizeof na);
+      na.M = N; na.h = h_in; na.agg = F(L.agg[l]); na.hout = F(L.h_e3[l]);
+      na.Wn1 = w[W_E3(l, E3_NN0_W)]; na.b1 = w[W_E3(l, E3_NN0_B)]; na.Wn2 = w[W_E3(l, E3_NN2_W)]; na.b2 = w[W_E3(l, E3_NN2_B)];
+      na.gamma = w[W_E3(l, E3_NN3_G)]; na.beta = w[W_E3(l, E3_NN3_B)];
+      const dim3 grid(ceil_div(N, 128));
+      PB("e3_%d.node_chain", l);
+      if (l < 2) {
+        na.Wt = w[W_E3(l + 1, E3_EN0_W)]; na.bt = edge_chain ? w[W_E3(l + 1, E3_EN0_B)] : nullptr; na.tout = F(L.P[l + 1]);
+        hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_PROJ, true>), grid, dim3(256), 0, s, na);
+      } else if (dit_chain) {
+        na.Wt = w[W_DIT(0, DIT_INP_W)]; na.bt = w[W_DIT(0, DIT_INP_B)]; na.tout = F(L.qkv[0]);
+        na.mod = F(L.mod[0]); na.mod_stride = mstride; na.atom_mol = g->atom_mol;
+        if (mstride == 0) hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_QKV, true>), grid, dim3(256), 0, s, na);
+        else hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_QKV, false>), grid, dim3(256), 0, s, na);
+      } else {
+        hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_NONE, true>), grid, dim3(256), 0, s, na);
+      }
+      PE();
+      h_in = F(L.h_e3[l]);
+      continue;
+    }
     {  // hid = SiLU([h | agg] Wn1^T + b)
       GemmCore gc = core_blocks(N, 512, 256, w[W_E3(l, E3_NN0_W)], 512, 1, 256);
       ALoadConcat al{h_in, F(L.agg[l]), 256, 256, 256, N, 512};
@@ -540,15 +570,19 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   // --- adaLN attention layers over each molecule's own atoms (model1.py:728-738, :279-302)
   const int max_n = g->max_mol_atoms;
   const float* x_in = h_in;
-  PB("dit0.ln_mod");
-  hipLaunchKernelGGL(k_ln_mod, dim3(ceil_div(N, 16)), dim3(256), 0, s, x_in, F(L.mod[0]), mstride, 0, 256,
-                     g->atom_mol, F(L.xn1[0]), N);
-  PE();
-  for (int l = 0; l < 3; ++l) {
-    PB("dit%d.qkv", l);
-    gemm_bias_act<ACT_NONE, false>(F(L.xn1[l]), 256, N, 256, w[W_DIT(l, DIT_INP_W)], 256, w[W_DIT(l, DIT_INP_B)], 3,
-                                   F(L.qkv[l]), 768, nullptr, s);
+  if (!dit_chain) {
+    PB("dit0.ln_mod");
+    hipLaunchKernelGGL(k_ln_mod, dim3(ceil_div(N, 16)), dim3(256), 0, s, x_in, F(L.mod[0]), mstride, 0, 256,
+                       g->atom_mol, F(L.xn1[0]), N);
     PE();
+  }
+  for (int l = 0; l < 3; ++l) {
+    if (!dit_chain) {
+      PB("dit%d.qkv", l);
+      gemm_bias_act<ACT_NONE, false>(F(L.xn1[l]), 256, N, 256, w[W_DIT(l, DIT_INP_W)], 256, w[W_DIT(l, DIT_INP_B)], 3,
+                                     F(L.qkv[l]), 768, nullptr, s);
+      PE();
+    }
     PB("dit%d.attention", l);
     {
       const int tk = (max_n + 31) / 32;
@@ -587,6 +621,30 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         hipLaunchKernelGGL(k_attention_mfma<4>, dim3(blocks), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]), S(L.lse[l]), B);
     }
     PE();
+    if (dit_chain) {
+      DitChainArgs da;
+      memset(&da, 0, sizeof da);
+      da.M = N; da.att = F(L.att[l]); da.x = x_in; da.xout = F(L.x2[l]);
+      da.Wo = w[W_DIT(l, DIT_OUT_W)]; da.bo = w[W_DIT(l, DIT_OUT_B)];
+      da.W1 = w[W_DIT(l, DIT_FF0_W)]; da.b1 = w[W_DIT(l, DIT_FF0_B)]; da.W2 = w[W_DIT(l, DIT_FF3_W)]; da.b2 = w[W_DIT(l, DIT_FF3_B)];
+      da.mod = F(L.mod[l]); da.mod_stride = mstride; da.atom_mol = g->atom_mol;
+      if (l < 2) {
+        da.mod_next = F(L.mod[l + 1]); da.Wqkv = w[W_DIT(l + 1, DIT_INP_W)]; da.bqkv = w[W_DIT(l + 1, DIT_INP_B)];
+        da.qkv = F(L.qkv[l + 1]);
+      }
+      const dim3 grid(ceil_div(N, 128));
+      PB("dit%d.chain", l);
+      if (mstride == 0) {
+        if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<true, true>), grid, dim3(256), 0, s, da);
+        else hipLaunchKernelGGL((dit_chain_kernel<true, false>), grid, dim3(256), 0, s, da);
+      } else {
+        if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<false, true>), grid, dim3(256), 0, s, da);
+        else hipLaunchKernelGGL((dit_chain_kernel<false, false>), grid, dim3(256), 0, s, da);
+      }
+      PE();
+      x_in = F(L.x2[l]);
+      continue;
+    }
     {  // x1 = x + gate_msa * (att Wo^T + b);  xn2 = LN(x1)(1+scale_mlp)+shift_mlp
       GemmCore gc = core_blocks(N, 256, 256, w[W_DIT(l, DIT_OUT_W)], 256, 1, 256);
       EpiGate<true> e{N, w[W_DIT(l, DIT_OUT_B)], x_in, F(L.mod[l]), mstride, 512, F(L.mod[l]), 768, 1024,

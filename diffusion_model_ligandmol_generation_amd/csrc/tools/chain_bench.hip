@@ -13,6 +13,9 @@
 #include "../gemm3.h"
 #include "../ffn_chain.h"
 #include "../edge_chain.h"
+#include "../dit_chain.h"
+#include "../node_chain.h"
+#include "../kernels.h"
 
 // register-only MFMA streams, one wave per SIMD: NACC accumulators used round-robin
 template <int NACC>
@@ -214,7 +217,176 @@ static void edge_test(int N, int E) {
          fl / (t1 * 1e-3) / 1e12);
 }
 
+// everything between two attention kernels: out-projection launch + fused feed-forward launch + in-projection launch
+// against the one fused kernel
+static void dit_test(int M, int stride) {
+  const int B = 1024;
+  float* att = dev_rand((size_t)M * 256, 1.0f, 31);
+  float* x = dev_rand((size_t)M * 256, 1.0f, 32);
+  float* Wo = dev_rand((size_t)256 * 256, 0.0625f, 33);
+  float* bo = dev_rand(256, 0.1f, 34);
+  float* W1 = dev_rand((size_t)1024 * 256, 0.0625f, 35);
+  float* b1 = dev_rand(1024, 0.1f, 36);
+  float* W2 = dev_rand((size_t)256 * 1024, 0.03125f, 37);
+  float* b2 = dev_rand(256, 0.1f, 38);
+  float* Wq = dev_rand((size_t)768 * 256, 0.0625f, 39);
+  float* bq = dev_rand(768, 0.1f, 40);
+  float* mod = dev_rand((size_t)B * 1536, 0.5f, 41);
+  float* modn = dev_rand((size_t)B * 1536, 0.5f, 42);
+  std::vector<int> hm(M);
+  for (int i = 0; i < M; ++i) hm[i] = (int)((long long)i * B / M);
+  int* mol;
+  CK(hipMalloc(&mol, M * 4));
+  CK(hipMemcpy(mol, hm.data(), M * 4, hipMemcpyHostToDevice));
+  float *X1, *XN2, *X2a, *XN1, *QA, *X2b, *QB;
+  CK(hipMalloc(&X1, (size_t)M * 256 * 4)); CK(hipMalloc(&XN2, (size_t)M * 256 * 4)); CK(hipMalloc(&X2a, (size_t)M * 256 * 4));
+  CK(hipMalloc(&XN1, (size_t)M * 256 * 4)); CK(hipMalloc(&QA, (size_t)M * 768 * 4));
+  CK(hipMalloc(&X2b, (size_t)M * 256 * 4)); CK(hipMalloc(&QB, (size_t)M * 768 * 4));
+  const int nblk = (M + 127) / 128;
+  GemmCore g0; memset(&g0, 0, sizeof g0);
+  g0.M = M; g0.K = 256; g0.n_valid = 256; g0.ldw = 256; g0.W[0] = Wo;
+  EpiGate<true> e0{M, bo, x, mod, stride, 512, mod, 768, 1024, mol, X1, XN2, nullptr};
+  FfnChainArgs fa{M, XN2, W1, b1, W2, b2, X1, mod, stride, 1280, modn, 0, 256, mol, X2a, XN1, nullptr};
+  GemmCore g2; memset(&g2, 0, sizeof g2);
+  g2.M = M; g2.K = 256; g2.n_valid = 256; g2.ldw = 256;
+  for (int i = 0; i < 3; ++i) g2.W[i] = Wq + (size_t)i * 256 * 256;
+  EpiBiasAct<8, ACT_NONE, false> e2; memset(&e2, 0, sizeof e2);
+  e2.M = M; e2.n_valid = 256; e2.col_block = 256; e2.C = QA; e2.ldc = 768; e2.alpha = 1.f;
+  for (int i = 0; i < 3; ++i) e2.bias[i] = bq + i * 256;
+  auto three = [&] {
+    hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiGate<true>>), dim3(nblk, 1), dim3(512), 0, 0, g0, APtrPlain{att, 256}, e0);
+    hipLaunchKernelGGL(ffn_chain_kernel<true>, dim3(nblk), dim3(256), 0, 0, fa);
+    hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiBiasAct<8, ACT_NONE, false>>), dim3(nblk, 3), dim3(512), 0, 0, g2, APtrPlain{XN1, 256}, e2);
+  };
+  unsigned long long* stamps;
+  CK(hipMalloc(&stamps, (size_t)nblk * 8 * 8));
+  DitChainArgs da{M, att, x, X2b, Wo, bo, W1, b1, W2, b2, mod, stride, modn, mol, Wq, bq, QB, stamps};
+  auto one = [&] {
+    if (stride == 0) hipLaunchKernelGGL((dit_chain_kernel<true, true>), dim3(nblk), dim3(256), 0, 0, da);
+    else hipLaunchKernelGGL((dit_chain_kernel<false, true>), dim3(nblk), dim3(256), 0, 0, da);
+  };
+  three(); one();
+  CK(hipDeviceSynchronize());
+  double m1, m2;
+  const float d1 = max_diff(X2a, X2b, (size_t)M * 256, &m1);
+  const float d2 = max_diff(QA, QB, (size_t)M * 768, &m2);
+  printf("attention-layer tail M=%d mod_stride=%d: max |x2 diff| %.3e (max |x2| %.3f)  max |qkv diff| %.3e (max %.3f)\n", M, stride, d1, m1, d2, m2);
+  if (stride == 0) {
+    hipLaunchKernelGGL((dit_chain_kernel<true, true, true>), dim3(nblk), dim3(256), 0, 0, da);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st((size_t)nblk * 8);
+    CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> ph[6];
+    for (int b = 0; b < nblk; ++b)
+      for (int k = 0; k < 6; ++k) ph[k].push_back((double)(st[b * 8 + k + 1] - st[b * 8 + k]));
+    auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    printf("  stamps (median cycles of wave 0): prologue %.0f, out-proj 8 steps %.0f (ideal 66560), gate+LN %.0f, FFN 64 steps %.0f (ideal 532480), gate+LN %.0f, in-proj 24 steps %.0f (ideal 199680)\n",
+           med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]), med(ph[5]));
+  }
+  const float t3 = time_it(three, 10), t1 = time_it(one, 10);
+  const double fl = 2.0 * M * (256.0 * 256 + 2.0 * 256 * 1024 + 256.0 * 768);
+  printf("  three launches %8.1f us (%6.1f TFLOP/s)   fused %8.1f us (%6.1f TFLOP/s)\n", t3 * 1e3, fl / (t3 * 1e-3) / 1e12, t1 * 1e3,
+         fl / (t1 * 1e-3) / 1e12);
+}
+
+// node update of an E(3) layer + what follows it (next layer's per-node edge projections, or the first
+// attention layer's pre-norm and in-projection): separate launches against the fused kernel
+static void node_test(int M, int tail, int stride) {
+  const int B = 1024;
+  float* hin = dev_rand((size_t)M * 256, 1.0f, 51);
+  float* agg = dev_rand((size_t)M * 256, 1.0f, 52);
+  float* Wn1 = dev_rand((size_t)256 * 512, 0.05f, 53);
+  float* b1 = dev_rand(256, 0.1f, 54);
+  float* Wn2 = dev_rand((size_t)256 * 256, 0.0625f, 55);
+  float* b2 = dev_rand(256, 0.1f, 56);
+  float* gamma = dev_rand(256, 1.0f, 57);
+  float* beta = dev_rand(256, 0.1f, 58);
+  float* Wen0 = dev_rand((size_t)256 * 544, 0.05f, 59);
+  float* b1e = dev_rand(256, 0.1f, 60);
+  float* Wq = dev_rand((size_t)768 * 256, 0.0625f, 61);
+  float* bq = dev_rand(768, 0.1f, 62);
+  float* mod = dev_rand((size_t)B * 1536, 0.5f, 63);
+  std::vector<int> hm(M);
+  for (int i = 0; i < M; ++i) hm[i] = (int)((long long)i * B / M);
+  int* mol;
+  CK(hipMalloc(&mol, M * 4));
+  CK(hipMemcpy(mol, hm.data(), M * 4, hipMemcpyHostToDevice));
+  const int ldt = tail == NODE_TAIL_PROJ ? 512 : 768;
+  float *hid, *hA, *hB, *xn, *tA, *tB;
+  CK(hipMalloc(&hid, (size_t)M * 256 * 4)); CK(hipMalloc(&hA, (size_t)M * 256 * 4)); CK(hipMalloc(&hB, (size_t)M * 256 * 4));
+  CK(hipMalloc(&xn, (size_t)M * 256 * 4)); CK(hipMalloc(&tA, (size_t)M * ldt * 4)); CK(hipMalloc(&tB, (size_t)M * ldt * 4));
+  const int nblk = (M + 127) / 128;
+  GemmCore g0; memset(&g0, 0, sizeof g0);
+  g0.M = M; g0.K = 512; g0.n_valid = 256; g0.ldw = 512; g0.W[0] = Wn1;
+  APtrConcat ap0{hin, agg, 256, 256, 256};
+  EpiBiasAct<8, ACT_SILU, false> e0; memset(&e0, 0, sizeof e0);
+  e0.M = M; e0.n_valid = 256; e0.col_block = 256; e0.bias[0] = b1; e0.C = hid; e0.ldc = 256; e0.alpha = 1.f;
+  GemmCore g1; memset(&g1, 0, sizeof g1);
+  g1.M = M; g1.K = 256; g1.n_valid = 256; g1.ldw = 256; g1.W[0] = Wn2;
+  EpiLN<ACT_NONE, ACT_NONE, true> e1; memset(&e1, 0, sizeof e1);
+  e1.M = M; e1.bias[0] = b2; e1.gamma[0] = gamma; e1.beta[0] = beta; e1.eps = 1e-5f; e1.C = hA; e1.ldc = 256; e1.resid = hin; e1.ldr = 256;
+  GemmCore g2; memset(&g2, 0, sizeof g2);
+  EpiBiasAct<8, ACT_NONE, false> e2; memset(&e2, 0, sizeof e2);
+  e2.M = M; e2.n_valid = 256; e2.col_block = 256; e2.C = tA; e2.ldc = ldt; e2.alpha = 1.f;
+  g2.M = M; g2.K = 256; g2.n_valid = 256;
+  if (tail == NODE_TAIL_PROJ) { g2.ldw = 544; g2.W[0] = Wen0; g2.W[1] = Wen0 + 256; e2.bias[1] = b1e; }
+  else { g2.ldw = 256; for (int i = 0; i < 3; ++i) { g2.W[i] = Wq + (size_t)i * 256 * 256; e2.bias[i] = bq + i * 256; } }
+  auto sep = [&] {
+    hipLaunchKernelGGL((gemm_cs_kernel<APtrConcat, EpiBiasAct<8, ACT_SILU, false>>), dim3(nblk, 1), dim3(512), 0, 0, g0, ap0, e0);
+    hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiLN<ACT_NONE, ACT_NONE, true>>), dim3(nblk, 1), dim3(512), 0, 0, g1, APtrPlain{hid, 256}, e1);
+    if (tail == NODE_TAIL_PROJ) {
+      hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiBiasAct<8, ACT_NONE, false>>), dim3(nblk, 2), dim3(512), 0, 0, g2, APtrPlain{hA, 256}, e2);
+    } else {
+      hipLaunchKernelGGL(k_ln_mod, dim3((M + 15) / 16), dim3(256), 0, 0, hA, mod, stride, 0, 256, mol, xn, M);
+      hipLaunchKernelGGL((gemm_cs_kernel<APtrPlain, EpiBiasAct<8, ACT_NONE, false>>), dim3(nblk, 3), dim3(512), 0, 0, g2, APtrPlain{xn, 256}, e2);
+    }
+  };
+  unsigned long long* stamps;
+  CK(hipMalloc(&stamps, (size_t)nblk * 8 * 8));
+  NodeChainArgs na{M, hin, agg, hB, Wn1, b1, Wn2, b2, gamma, beta, tail == NODE_TAIL_PROJ ? Wen0 : Wq, tail == NODE_TAIL_PROJ ? b1e : bq, tB, mod, stride, mol, stamps};
+  auto one = [&] {
+    if (tail == NODE_TAIL_PROJ) hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_PROJ, true>), dim3(nblk), dim3(256), 0, 0, na);
+    else if (stride == 0) hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_QKV, true>), dim3(nblk), dim3(256), 0, 0, na);
+    else hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_QKV, false>), dim3(nblk), dim3(256), 0, 0, na);
+  };
+  sep(); one();
+  CK(hipDeviceSynchronize());
+  double m1, m2;
+  const float d1 = max_diff(hA, hB, (size_t)M * 256, &m1);
+  const float d2 = max_diff(tA, tB, (size_t)M * ldt, &m2);
+  printf("node update M=%d tail=%s mod_stride=%d: max |h diff| %.3e (max |h| %.3f)  max |tail diff| %.3e (max %.3f)\n", M,
+         tail == NODE_TAIL_PROJ ? "edge projections" : "pre-norm + in-projection", stride, d1, m1, d2, m2);
+  if (tail == NODE_TAIL_PROJ) {
+    hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_PROJ, true, true>), dim3(nblk), dim3(256), 0, 0, na);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st((size_t)nblk * 8);
+    CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> ph[6];
+    for (int b = 0; b < nblk; ++b)
+      for (int k = 0; k < 6; ++k) ph[k].push_back((double)(st[b * 8 + k + 1] - st[b * 8 + k]));
+    auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    printf("  stamps (median cycles of wave 0): prologue %.0f, agg half %.0f, h half + SiLU %.0f, second linear %.0f (ideal 66560 each), LN + residual %.0f, tail 16 steps %.0f (ideal 133120)\n",
+           med(ph[0]), med(ph[1]), med(ph[2]), med(ph[3]), med(ph[4]), med(ph[5]));
+  }
+  const float t3 = time_it(sep, 10), t1 = time_it(one, 10);
+  const double fl = 2.0 * M * (512.0 * 256 + 256.0 * 256 + 256.0 * ldt);
+  printf("  separate launches %8.1f us (%6.1f TFLOP/s)   fused %8.1f us (%6.1f TFLOP/s)\n", t3 * 1e3, fl / (t3 * 1e-3) / 1e12, t1 * 1e3,
+         fl / (t1 * 1e-3) / 1e12);
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && strcmp(argv[1], "node") == 0) {
+    node_test(29696, NODE_TAIL_PROJ, 0);
+    node_test(29696, NODE_TAIL_QKV, 0);
+    node_test(29696 - 50, NODE_TAIL_QKV, 1536);
+    return 0;
+  }
+  if (argc > 1 && strcmp(argv[1], "dit") == 0) {
+    dit_test(29696, 0);
+    dit_test(29696, 1536);
+    dit_test(29696 - 50, 0);
+    return 0;
+  }
   if (argc > 1 && strcmp(argv[1], "edge") == 0) {
     edge_test(29696, 63488);
     edge_test(29696, 63488 - 77);

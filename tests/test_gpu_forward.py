@@ -86,7 +86,12 @@ def test_forward_matches_oracle_ragged(sizes, fc):
                                                          pad_to_max_atoms=False, return_intermediates=True)
         a, p, r, _ = m(Bag(x=x.cuda(), pos=pos.cuda(), edge_index=ei.cuda(), batch=b.cuda()), t.cuda())
     torch.testing.assert_close(a.cpu(), ea, rtol=RTOL, atol=ATOL)
-    torch.testing.assert_close(p.cpu(), ep, rtol=RTOL, atol=ATOL)
+    # A coordinate prediction is a sum over the atom's neighbours; in a fully connected 100-atom ligand with
+    # random weights the terms reach several hundred and cancel, so the fp32 summation-order noise of an
+    # element follows the largest coordinate of the batch, not the element's own size (the separate-launch
+    # and the fused kernels sit at the same 1.2e-6 of that scale against the oracle).
+    pos_atol = max(ATOL, 2e-6 * float(ep.abs().max()))
+    torch.testing.assert_close(p.cpu(), ep, rtol=RTOL, atol=pos_atol)
     torch.testing.assert_close(r.cpu(), er, rtol=RTOL, atol=ATOL)
 
 

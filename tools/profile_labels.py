@@ -16,10 +16,10 @@ pos = torch.randn(g.n_atoms, 3, device="cuda")
 t = torch.tensor([500], dtype=torch.int32, device="cuda")
 labels = ["time.fourier", "time.mlp0", "time.mlp2", "dit.adaln", "embed"]
 for l in range(3):
-    labels += [f"e3_{l}.{k}" for k in ("node_proj", "edge_geom", "edge_pre", "edge_mlp2", "coord", "edge_chain", "aggregate", "node_mlp1", "node_mlp2")]
+    labels += [f"e3_{l}.{k}" for k in ("node_proj", "edge_geom", "edge_pre", "edge_mlp2", "coord", "edge_chain", "aggregate", "node_mlp1", "node_mlp2", "node_chain")]
 labels += ["dit0.ln_mod"]
 for l in range(3):
-    labels += [f"dit{l}.{k}" for k in ("qkv", "attention", "out_proj", "ffn_up", "ffn_down", "ffn")]
+    labels += [f"dit{l}.{k}" for k in ("qkv", "attention", "out_proj", "ffn_up", "ffn_down", "ffn", "chain")]
 labels += ["head.hidden", "head.atom", "head.pos"]
 tot = 0.0
 for lab in labels:
