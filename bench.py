@@ -448,6 +448,25 @@ def run_rank(args):
 
         def ffn_up_roofline(split):
             eng.set_split_gemm(split)
+            if not split:
+                # fp32 pipe: the dominant launch is the fused attention-layer tail (out-projection, feed-forward
+                # block, next layer's pre-norm and in-projection); LIGDIFF_NO_CHAIN=1 brings the separate
+                # launches back and the feed-forward up-projection is then the largest one
+                try:
+                    eng.time_launch("dit1.chain", graph, x, pos, t_index, reps=2)    # warm
+                    ms = eng.time_launch("dit1.chain", graph, x, pos, t_index, reps=10)
+                    eng.set_split_gemm(split_mode)
+                    flops = 2.0 * N * (256 * 256 + 2 * 256 * 1024 + 256 * 768)
+                    ach = flops / (ms * 1e-3) / 1e12
+                    return {"kernel": "dit_chain_kernel<true, true> (dit*.chain: out-projection + gated residual + LN, FFN "
+                                      "256-1024-256 with GELU, gated residual + next layer's LN and in-projection 256-768; "
+                                      f"M={N})",
+                            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "flops_per_launch": flops,
+                            "traffic": traffic_of(traffic, "dit_chain_kernel<true, true"),
+                            "traffic_source": traffic_src, "avg_launch_ms": ms}
+                except Exception:   # noqa: BLE001  (label not present: chain kernels switched off)
+                    pass
             eng.time_launch("dit1.ffn_up", graph, x, pos, t_index, reps=2)           # warm
             ms = eng.time_launch("dit1.ffn_up", graph, x, pos, t_index, reps=10)
             eng.set_split_gemm(split_mode)
