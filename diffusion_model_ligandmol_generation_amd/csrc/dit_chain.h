@@ -2,7 +2,9 @@
 //   x1  = x + gate_msa * (att Wo^T + bo)
 //   xn2 = LN(x1; eps 1e-6, no affine) (1 + scale_mlp) + shift_mlp
 //   x2  = x1 + gate_mlp * (GELU(xn2 W1^T + b1) W2^T + b2)                       -> HBM (residual stream)
-//   TAIL_QKV:  qkv' = (LN(x2) (1 + scale_msa') + shift_msa') Wqkv'^T + bqkv'   -> HBM (the NEXT layer's attention input)
+//   DIT_TAIL_QKV:    qkv' = (LN(x2) (1 + scale_msa') + shift_msa') Wqkv'^T + bqkv'   -> HBM (the NEXT layer's attention input)
+//   DIT_TAIL_HEADS:  y_k = LN(GELU(x2 W0_k^T + b0_k); eps 1e-5) g_k + be_k for the atom and the coordinate head (model1.py:636-655),
+//                    atom_pred = y_a W3a^T + b3a [M,119],  pos_pred = y_p W3p^T + b3p + pos_upd [M,3]        -> HBM
 // i.e. everything between two attention kernels as ONE launch; x1 makes one round trip through HBM
 // (written behind the first feed-forward step, read back behind the last), the [M,1024] hidden
 // activations, xn2 and the next layer's pre-norm never leave the registers (layout: chain.h).
@@ -11,7 +13,8 @@
 // s in buffer s & 3, fetched two steps ahead behind the MFMAs of step s - 2:
 //   s = 0..7          WIDE tiles of Wo          (out-projection, one output tile each)
 //   s = 8 + 2t, 9 + 2t  WIDE tile t of W1, TALL tile t of W2   (t = 0..31)
-//   s = 72 + q        WIDE tiles of Wqkv'       (q = 0..23, TAIL_QKV)
+//   s = 72 + q        WIDE tiles of Wqkv'       (q = 0..23, DIT_TAIL_QKV)
+//   s = 72..79, 80..83, 84..91   WIDE tiles of W0_atom, W3_atom (rows clamped to 119), W0_pos   (DIT_TAIL_HEADS)
 // The small vectors (adaLN rows when all molecules share the timestep, biases) are staged in LDS once.
 #pragma once
 #include "chain.h"
@@ -26,7 +29,13 @@ struct DitChainArgs {
   const float* mod; int mod_stride;   // this layer's adaLN rows [B or 1, stride]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
   const float* mod_next;              // the next layer's rows (TAIL_QKV): shift_msa | scale_msa | ...
   const int32_t* atom_mol;
-  const float* Wqkv; const float* bqkv; float* qkv;   // TAIL_QKV: next layer's in_proj, output [M,768]
+  const float* Wqkv; const float* bqkv; float* qkv;   // DIT_TAIL_QKV: next layer's in_proj, output [M,768]
+  // DIT_TAIL_HEADS: hidden layers (Linear 256-256, GELU, LayerNorm) and output layers of the atom / coordinate heads
+  const float* W0a; const float* b0a; const float* ga; const float* bea; const float* W3a; const float* b3a;
+  const float* W0p; const float* b0p; const float* gp; const float* bep; const float* W3p; const float* b3p;
+  const float* pos_upd;   // [M,3] accumulated coordinate updates of the E(3) layers
+  float* atom_pred;       // [M,119]
+  float* pos_pred;        // [M,3]
   unsigned long long* stamps;   // diagnostic builds (DBG): [grid][8] shader-clock stamps of wave 0
 };
 
@@ -57,12 +66,19 @@ __device__ __forceinline__ void gelu_tile(f32x16& u) {
 #define DC_VEC_BO 2048
 #define DC_VEC_B2 2304
 #define DC_VEC_B1 2560      // 1024
-#define DC_VEC_BQKV 3584    // 768
-#define DC_VEC_FL 4352
+#define DC_VEC_BQKV 3584    // 768 (DIT_TAIL_QKV); DIT_TAIL_HEADS puts its vectors here:
+#define DC_VEC_HB0 3584     //   [2][256] hidden bias (atom, pos)
+#define DC_VEC_HG 4096      //   [2][256] LayerNorm weight
+#define DC_VEC_HBE 4608     //   [2][256] LayerNorm bias
+#define DC_VEC_B3A 5120     //   128: atom head output bias (119 valid)
+#define DC_VEC_W3P 5248     //   [3][256] coordinate head output weight
+#define DC_VEC_FL 6016
+enum { DIT_TAIL_NONE = 0, DIT_TAIL_QKV = 1, DIT_TAIL_HEADS = 2 };
 
-template <bool SHARED, bool TAIL_QKV, bool DBG = false>   // SHARED: mod_stride == 0 (one adaLN row set for all molecules)
+template <bool SHARED, int TAIL, bool DBG = false>   // SHARED: mod_stride == 0 (one adaLN row set for all molecules)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void dit_chain_kernel(DitChainArgs p) {
+  constexpr bool TAIL_QKV = TAIL == DIT_TAIL_QKV;
   __shared__ __attribute__((aligned(1024))) float smem[4 * CH_TILE_FL + DC_VEC_FL];
   float* const vec = smem + 4 * CH_TILE_FL;
   const int tid = threadIdx.x;
@@ -85,22 +101,64 @@ void dit_chain_kernel(DitChainArgs p) {
       if (s & 1) cl.dma_tall(p.W2, 1024, 32 * t, buf, n);
       else cl.dma_wide(p.W1, 256, 32 * t, 1024, 0, buf, n);
     } else if (TAIL_QKV) cl.dma_wide(p.Wqkv, 256, 32 * (s - 72), 768, 0, buf, n);
+    else if (TAIL == DIT_TAIL_HEADS) {
+      if (s < 80) cl.dma_wide(p.W0a, 256, 32 * (s - 72), 256, 0, buf, n);
+      else if (s < 84) cl.dma_wide(p.W3a, 256, 32 * (s - 80), 119, 0, buf, n);
+      else cl.dma_wide(p.W0p, 256, 32 * (s - 84), 256, 0, buf, n);
+    }
   };
-  constexpr int S_END = TAIL_QKV ? 96 : 72;
+  constexpr int S_END = TAIL_QKV ? 96 : TAIL == DIT_TAIL_HEADS ? 92 : 72;
 #pragma unroll
   for (int n = 0; n < 8; ++n) { fetch(0, n); fetch(1, n); }
 
-  // small vectors -> LDS
-  auto stage = [&](const float* src, int off, int nfl) {
-    for (int i = tid * 4; i < nfl; i += 1024) *reinterpret_cast<f32x4*>(vec + off + i) = *reinterpret_cast<const f32x4*>(src + i);
-  };
-  if (SHARED) {
-    stage(p.mod, DC_VEC_MOD, 1536);
-    if (TAIL_QKV) stage(p.mod_next, DC_VEC_MODN, 512);
+  // small vectors -> LDS (all loads first, then the writes)
+  {
+    constexpr int NV = TAIL == DIT_TAIL_HEADS ? 896 : 1088;   // float4 slots
+    f32x4 v[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int idx = tid + 256 * i;
+      const float* src = nullptr;
+      if (idx < 384) src = SHARED ? p.mod + idx * 4 : nullptr;
+      else if (idx < 512) src = (SHARED && TAIL_QKV) ? p.mod_next + (idx - 384) * 4 : nullptr;
+      else if (idx < 576) src = p.bo + (idx - 512) * 4;
+      else if (idx < 640) src = p.b2 + (idx - 576) * 4;
+      else if (idx < 896) src = p.b1 + (idx - 640) * 4;
+      else if (idx < 1088) src = TAIL_QKV ? p.bqkv + (idx - 896) * 4 : nullptr;
+      v[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < NV) *reinterpret_cast<f32x4*>(vec + idx * 4) = v[i];
+    }
   }
-  stage(p.bo, DC_VEC_BO, 256); stage(p.b2, DC_VEC_B2, 256); stage(p.b1, DC_VEC_B1, 1024);
-  if (TAIL_QKV) stage(p.bqkv, DC_VEC_BQKV, 768);
 
+  if (TAIL == DIT_TAIL_HEADS) {   // the heads' vectors (float4 slots 896 ..): 128 x 6 hidden-layer vectors, 32 b3a, 192 W3p
+    f32x4 v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + 256 * i;
+      const float* src = nullptr;
+      if (idx < 64) src = p.b0a + idx * 4;
+      else if (idx < 128) src = p.b0p + (idx - 64) * 4;
+      else if (idx < 192) src = p.ga + (idx - 128) * 4;
+      else if (idx < 256) src = p.gp + (idx - 192) * 4;
+      else if (idx < 320) src = p.bea + (idx - 256) * 4;
+      else if (idx < 384) src = p.bep + (idx - 320) * 4;
+      else if (idx >= 416 && idx < 608) src = p.W3p + (idx - 416) * 4;
+      v[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (idx >= 384 && idx < 416) {   // 119 floats: not a multiple of four
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[i][k] = (idx - 384) * 4 + k < 119 ? p.b3a[(idx - 384) * 4 + k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < 608) *reinterpret_cast<f32x4*>(vec + DC_VEC_HB0 + idx * 4) = v[i];
+    }
+  }
   // adaLN vector `off` (0 shift_msa .. 1280 gate_mlp), features 8m + 4h .. + 3, for this lane's molecule
   const float* const mrow = SHARED ? nullptr : p.mod + (size_t)p.atom_mol[rr] * p.mod_stride + 4 * h;
   const float* const mrow_n = (SHARED || !TAIL_QKV) ? nullptr : p.mod_next + (size_t)p.atom_mol[rr] * p.mod_stride + 4 * h;
@@ -114,14 +172,13 @@ void dit_chain_kernel(DitChainArgs p) {
   };
   auto vec4 = [&](int off, int m) -> f32x4 { return *reinterpret_cast<const f32x4*>(vec + off + 8 * m + 4 * h); };
 
-  unsigned at[4][4], aw[4][8];
+  // fragment addresses: buffers 0 / 1 and 2 / 3 share a base each (the odd one sits 32 KiB further, inside
+  // the 16-bit instruction offset); a register per address and buffer costs 48 registers and spills
+  unsigned at2[4], aw2[8];
 #pragma unroll
-  for (int bf = 0; bf < 4; ++bf) {
+  for (int g = 0; g < 4; ++g) at2[g] = cl.a_tall[g] + 2 * CH_TILE_FL * 4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) at[bf][g] = cl.a_tall[g] + bf * CH_TILE_FL * 4;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) aw[bf][k] = cl.a_wide[k] + bf * CH_TILE_FL * 4;
-  }
+  for (int k = 0; k < 8; ++k) aw2[k] = cl.a_wide[k] + 2 * CH_TILE_FL * 4;
   // every step opens with: all of this wave's memory operations done (the tile fetched during the
   // previous step among them), then the workgroup barrier (everybody is done with the buffer that this
   // step's fetch refills, and everybody's pieces of this step's tile have landed one step earlier)
@@ -134,7 +191,11 @@ void dit_chain_kernel(DitChainArgs p) {
   auto wide_step = [&](auto BF, int s, f32x16& acc, f32x16 (&xs)[8], auto&& extra) {
     constexpr int bf = decltype(BF)::value;
     chain_groups<32>(
-        [&](auto J) { constexpr int j = decltype(J)::value; return lds_read128<(j >> 3) * 256>(aw[bf][j & 7]); },
+        [&](auto J) {
+          constexpr int j = decltype(J)::value;
+          if constexpr (bf < 2) return lds_read128<(j >> 3) * 256 + bf * CH_TILE_FL * 4>(cl.a_wide[j & 7]);
+          else return lds_read128<(j >> 3) * 256 + (bf - 2) * CH_TILE_FL * 4>(aw2[j & 7]);
+        },
         [&](auto J) {
           constexpr int m = decltype(J)::value;
           return f32x4{xs[m >> 2][4 * (m & 3)], xs[m >> 2][4 * (m & 3) + 1], xs[m >> 2][4 * (m & 3) + 2], xs[m >> 2][4 * (m & 3) + 3]};
@@ -149,7 +210,11 @@ void dit_chain_kernel(DitChainArgs p) {
   auto tall_step = [&](auto BF, int s, f32x16 (&out)[8], f32x16& u, auto&& extra) {
     constexpr int bf = decltype(BF)::value;
     chain_groups<32>(
-        [&](auto J) { constexpr int j = decltype(J)::value; return lds_read128<(j >> 2) * 4096>(at[bf][j & 3]); },
+        [&](auto J) {
+          constexpr int j = decltype(J)::value;
+          if constexpr (bf < 2) return lds_read128<(j >> 2) * 4096 + bf * CH_TILE_FL * 4>(cl.a_tall[j & 3]);
+          else return lds_read128<(j >> 2) * 4096 + (bf - 2) * CH_TILE_FL * 4>(at2[j & 3]);
+        },
         [&](auto J) { constexpr int g = decltype(J)::value & 3; return f32x4{u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]}; },
         [&](auto J) -> f32x16& { return out[decltype(J)::value >> 2]; },
         [&](auto J) {
@@ -279,8 +344,83 @@ void dit_chain_kernel(DitChainArgs p) {
       *reinterpret_cast<f32x4*>(xrow_out + 8 * j) =
           f32x4{x1[j >> 2][4 * (j & 3)], x1[j >> 2][4 * (j & 3) + 1], x1[j >> 2][4 * (j & 3) + 2], x1[j >> 2][4 * (j & 3) + 3]};
   };
-  if (!TAIL_QKV) {
+  if constexpr (TAIL == DIT_TAIL_NONE) {
     static_for<0, 32>(store_x2);
+    return;
+  }
+  if constexpr (TAIL == DIT_TAIL_HEADS) {
+    // hidden layer of head HD: yh = LN(GELU(x2 W0^T + b0)) g + be   (ring steps S0 .. S0 + 7)
+    f32x16 yh[8];
+    auto head_hidden = [&](auto HD, auto S0) {
+      constexpr int hd = decltype(HD)::value, s0 = decltype(S0)::value;
+      static_for<0, 8>([&](auto O) {
+        constexpr int o = decltype(O)::value;
+        open_step();
+        init_tile(yh[o], DC_VEC_HB0 + hd * 256, o);
+        if (s0 + o == 72) wide_step(std::integral_constant<int, (s0 + o) & 3>{}, s0 + o, yh[o], x1, store_x2);
+        else wide_step(std::integral_constant<int, (s0 + o) & 3>{}, s0 + o, yh[o], x1, NoHook{});
+        gelu_tile(yh[o]);
+      });
+      float s = 0.f;
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += yh[o][r];
+      s += __shfl_xor(s, 32);
+      const float mean = s * (1.0f / 256.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = yh[o][r] - mean; q += d * d; }
+      q += __shfl_xor(q, 32);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+      for (int m = 0; m < 32; ++m) {
+        const f32x4 gm = vec4(DC_VEC_HG + hd * 256, m), be = vec4(DC_VEC_HBE + hd * 256, m);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          yh[m >> 2][4 * (m & 3) + k] = ((yh[m >> 2][4 * (m & 3) + k] - mean) * rstd) * gm[k] + be[k];
+      }
+    };
+    head_hidden(std::integral_constant<int, 0>{}, std::integral_constant<int, 72>{});
+    // atom head output: four tiles of 32 columns (119 valid), row stride 119 floats -> dword stores
+    {
+      float* const arow = p.atom_pred + (size_t)rr * 119 + 4 * h;
+      static_for<0, 4>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+        f32x16 acc;
+        open_step();
+        init_tile(acc, DC_VEC_B3A, q);
+        wide_step(std::integral_constant<int, (80 + q) & 3>{}, 80 + q, acc, yh, NoHook{});
+        if (row < p.M) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (32 * q + 8 * g + 4 * h + k < 119) arow[32 * q + 8 * g + k] = acc[4 * g + k];
+        }
+      });
+    }
+    head_hidden(std::integral_constant<int, 1>{}, std::integral_constant<int, 84>{});
+    // coordinate head output: three dot products over the lane's 128 features, completed by the partner lane
+    {
+      float d[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 32; ++m)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+          const f32x4 w = vec4(DC_VEC_W3P + o * 256, m);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[o] += yh[m >> 2][4 * (m & 3) + k] * w[k];
+        }
+#pragma unroll
+      for (int o = 0; o < 3; ++o) d[o] += __shfl_xor(d[o], 32);
+      if (h == 0 && row < p.M) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) p.pos_pred[(size_t)row * 3 + o] = d[o] + p.b3p[o] + p.pos_upd[(size_t)row * 3 + o];
+      }
+    }
     return;
   }
 

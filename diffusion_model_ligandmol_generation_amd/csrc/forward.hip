@@ -634,12 +634,19 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       }
       const dim3 grid(ceil_div(N, 128));
       PB("dit%d.chain", l);
+      if (l == 2) {   // the last layer carries the atom and coordinate heads (model1.py:741-742)
+        da.W0a = w[W_HEAD(0, HEAD_W0)]; da.b0a = w[W_HEAD(0, HEAD_B0)]; da.ga = w[W_HEAD(0, HEAD_G)]; da.bea = w[W_HEAD(0, HEAD_BE)];
+        da.W3a = w[W_HEAD(0, HEAD_W3)]; da.b3a = w[W_HEAD(0, HEAD_B3)];
+        da.W0p = w[W_HEAD(1, HEAD_W0)]; da.b0p = w[W_HEAD(1, HEAD_B0)]; da.gp = w[W_HEAD(1, HEAD_G)]; da.bep = w[W_HEAD(1, HEAD_BE)];
+        da.W3p = w[W_HEAD(1, HEAD_W3)]; da.b3p = w[W_HEAD(1, HEAD_B3)];
+        da.pos_upd = F(L.pos_upd); da.atom_pred = atom_pred; da.pos_pred = pos_pred;
+      }
       if (mstride == 0) {
-        if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<true, true>), grid, dim3(256), 0, s, da);
-        else hipLaunchKernelGGL((dit_chain_kernel<true, false>), grid, dim3(256), 0, s, da);
+        if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_QKV>), grid, dim3(256), 0, s, da);
+        else hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_HEADS>), grid, dim3(256), 0, s, da);
       } else {
-        if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<false, true>), grid, dim3(256), 0, s, da);
-        else hipLaunchKernelGGL((dit_chain_kernel<false, false>), grid, dim3(256), 0, s, da);
+        if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<false, DIT_TAIL_QKV>), grid, dim3(256), 0, s, da);
+        else hipLaunchKernelGGL((dit_chain_kernel<false, DIT_TAIL_HEADS>), grid, dim3(256), 0, s, da);
       }
       PE();
       x_in = F(L.x2[l]);
@@ -723,6 +730,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   }
 
   // --- heads (model1.py:741-746)
+  if (!dit_chain) {
   {
     GemmCore gc;
     memset(&gc, 0, sizeof gc);
@@ -752,6 +760,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   hipLaunchKernelGGL(k_head_small<3>, dim3(ceil_div(N, 16)), dim3(256), 0, s, F(L.yh), 512, 256, w[W_HEAD(1, HEAD_W3)],
                      w[W_HEAD(1, HEAD_B3)], F(L.pos_upd), pos_pred, N);
   PE();
+  }
   if (!(flags & LIGDIFF_FWD_SKIP_PROP_HEAD)) {
     if (prop_pred == nullptr) return LIGDIFF_ERR_ARG;
     hipLaunchKernelGGL(k_mean_pool, dim3(ceil_div(B, 4)), dim3(256), 0, s, x_in, g->mol_ptr, F(L.pooled), B);

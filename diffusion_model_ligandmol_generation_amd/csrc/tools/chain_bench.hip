@@ -260,10 +260,12 @@ static void dit_test(int M, int stride) {
   };
   unsigned long long* stamps;
   CK(hipMalloc(&stamps, (size_t)nblk * 8 * 8));
-  DitChainArgs da{M, att, x, X2b, Wo, bo, W1, b1, W2, b2, mod, stride, modn, mol, Wq, bq, QB, stamps};
+  DitChainArgs da; memset(&da, 0, sizeof da);
+  da.M = M; da.att = att; da.x = x; da.xout = X2b; da.Wo = Wo; da.bo = bo; da.W1 = W1; da.b1 = b1; da.W2 = W2; da.b2 = b2;
+  da.mod = mod; da.mod_stride = stride; da.mod_next = modn; da.atom_mol = mol; da.Wqkv = Wq; da.bqkv = bq; da.qkv = QB; da.stamps = stamps;
   auto one = [&] {
-    if (stride == 0) hipLaunchKernelGGL((dit_chain_kernel<true, true>), dim3(nblk), dim3(256), 0, 0, da);
-    else hipLaunchKernelGGL((dit_chain_kernel<false, true>), dim3(nblk), dim3(256), 0, 0, da);
+    if (stride == 0) hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_QKV>), dim3(nblk), dim3(256), 0, 0, da);
+    else hipLaunchKernelGGL((dit_chain_kernel<false, DIT_TAIL_QKV>), dim3(nblk), dim3(256), 0, 0, da);
   };
   three(); one();
   CK(hipDeviceSynchronize());
@@ -272,7 +274,7 @@ static void dit_test(int M, int stride) {
   const float d2 = max_diff(QA, QB, (size_t)M * 768, &m2);
   printf("attention-layer tail M=%d mod_stride=%d: max |x2 diff| %.3e (max |x2| %.3f)  max |qkv diff| %.3e (max %.3f)\n", M, stride, d1, m1, d2, m2);
   if (stride == 0) {
-    hipLaunchKernelGGL((dit_chain_kernel<true, true, true>), dim3(nblk), dim3(256), 0, 0, da);
+    hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_QKV, true>), dim3(nblk), dim3(256), 0, 0, da);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st((size_t)nblk * 8);
     CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
