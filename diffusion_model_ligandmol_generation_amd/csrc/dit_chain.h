@@ -179,12 +179,16 @@ void dit_chain_kernel(DitChainArgs p) {
   for (int g = 0; g < 4; ++g) at2[g] = cl.a_tall[g] + 2 * CH_TILE_FL * 4;
 #pragma unroll
   for (int k = 0; k < 8; ++k) aw2[k] = cl.a_wide[k] + 2 * CH_TILE_FL * 4;
-  // every step opens with: all of this wave's memory operations done (the tile fetched during the
-  // previous step among them), then the workgroup barrier (everybody is done with the buffer that this
-  // step's fetch refills, and everybody's pieces of this step's tile have landed one step earlier)
-  auto open_step = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  // Every EVEN step opens with: all of this wave's memory operations done (the tiles fetched during the
+  // previous two steps among them), then the workgroup barrier.  With four buffers and a fetch distance
+  // of two that is enough for the odd step behind it as well: its tile was fetched two steps earlier, so
+  // its pieces were waited for before this barrier, and the buffer that its own fetch refills held the
+  // tile of the step before this barrier.
+  auto open_step = [&](bool even = true) {
+    if (even) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   };
   // one WIDE step: acc += tile(buffer BF) . slab, slab group m = xs[m >> 2] registers 4 (m & 3) ..;  the
   // fetch of tile s + 2 rides behind groups 8..15, extra(J) behind every group
@@ -271,7 +275,7 @@ void dit_chain_kernel(DitChainArgs p) {
   f32x16 x1[8];
   static_for<0, 8>([&](auto O) {
     constexpr int o = decltype(O)::value;
-    if (o > 0) open_step();
+    if (o > 0) open_step(!(o & 1));
     init_tile(x1[o], DC_VEC_BO, o);
     wide_step(std::integral_constant<int, o & 3>{}, o, x1[o], xs, NoHook{});
   });
@@ -315,13 +319,13 @@ void dit_chain_kernel(DitChainArgs p) {
 #pragma unroll
       for (int o = 0; o < 8; ++o) init_tile(out[o], DC_VEC_B2, o);
     }
-    open_step();
+    open_step(false);
     tall_step(std::integral_constant<int, 1>{}, 9 + 2 * t, out, u, NoHook{});
     open_step();
     init_tile(u, DC_VEC_B1, t + 1);
     wide_step(std::integral_constant<int, 2>{}, 10 + 2 * t, u, xs, NoHook{});
     gelu_tile(u);
-    open_step();
+    open_step(false);
     if (last) tall_step(std::integral_constant<int, 3>{}, 11 + 2 * t, out, u, load_x1);
     else tall_step(std::integral_constant<int, 3>{}, 11 + 2 * t, out, u, NoHook{});
   };
@@ -355,7 +359,7 @@ void dit_chain_kernel(DitChainArgs p) {
       constexpr int hd = decltype(HD)::value, s0 = decltype(S0)::value;
       static_for<0, 8>([&](auto O) {
         constexpr int o = decltype(O)::value;
-        open_step();
+        open_step(!((s0 + o) & 1));
         init_tile(yh[o], DC_VEC_HB0 + hd * 256, o);
         if (s0 + o == 72) wide_step(std::integral_constant<int, (s0 + o) & 3>{}, s0 + o, yh[o], x1, store_x2);
         else wide_step(std::integral_constant<int, (s0 + o) & 3>{}, s0 + o, yh[o], x1, NoHook{});
@@ -390,7 +394,7 @@ void dit_chain_kernel(DitChainArgs p) {
       static_for<0, 4>([&](auto Q) {
         constexpr int q = decltype(Q)::value;
         f32x16 acc;
-        open_step();
+        open_step(!(q & 1));
         init_tile(acc, DC_VEC_B3A, q);
         wide_step(std::integral_constant<int, (80 + q) & 3>{}, 80 + q, acc, yh, NoHook{});
         if (row < p.M) {
@@ -440,13 +444,13 @@ void dit_chain_kernel(DitChainArgs p) {
     init_tile(qa, DC_VEC_BQKV, q);
     if (first) wide_step(std::integral_constant<int, 0>{}, 72 + q, qa, xs, store_x2);
     else wide_step(std::integral_constant<int, 0>{}, 72 + q, qa, xs, [&](auto J) { store_q(qb, q - 1, J); });
-    open_step();
+    open_step(false);
     init_tile(qb, DC_VEC_BQKV, q + 1);
     wide_step(std::integral_constant<int, 1>{}, 73 + q, qb, xs, [&](auto J) { store_q(qa, q, J); });
     open_step();
     init_tile(qa, DC_VEC_BQKV, q + 2);
     wide_step(std::integral_constant<int, 2>{}, 74 + q, qa, xs, [&](auto J) { store_q(qb, q + 1, J); });
-    open_step();
+    open_step(false);
     init_tile(qb, DC_VEC_BQKV, q + 3);
     wide_step(std::integral_constant<int, 3>{}, 75 + q, qb, xs, [&](auto J) { store_q(qa, q + 2, J); });
   };

@@ -1,0 +1,38 @@
+"""The fused chain kernels of the inference path (ffn / edge / node / attention-layer tail, csrc/*_chain.h)
+against the separate-launch kernels they replace: the same forwards and one sampling call in two processes,
+one with LIGDIFF_NO_CHAIN=1.  Both paths are pinned to the reference by the other GPU tests (each runs with
+the default, fused, path); this one compares them directly, at shapes that exercise partial workgroups,
+one-atom-short tiles, per-molecule timesteps, property conditioning and fully connected edges."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(tmp_path, name, extra_env):
+    out = str(tmp_path / f"{name}.npz")
+    env = dict(os.environ)
+    env.pop("LIGDIFF_NO_CHAIN", None)
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_chain_ab.py"), out], env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+def test_chain_kernels_match_separate_launches(tmp_path):
+    fused = _run(tmp_path, "fused", {})
+    plain = _run(tmp_path, "plain", {"LIGDIFF_NO_CHAIN": "1"})
+    assert set(fused.files) == set(plain.files)
+    for k in fused.files:
+        a, b = fused[k], plain[k]
+        assert a.shape == b.shape and np.isfinite(a).all() and np.isfinite(b).all(), k
+        # fp32 summation orders differ between the two paths: tolerance relative to the tensor's scale
+        # (the sampled state after 25 reverse steps accumulates 25 forwards' worth of it)
+        scale = max(1.0, float(np.abs(b).max()))
+        tol = (2e-4 if k.startswith("s_") else 2e-5) * scale
+        assert float(np.abs(a - b).max()) <= tol, (k, float(np.abs(a - b).max()), scale)
