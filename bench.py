@@ -450,7 +450,7 @@ def run_rank(args):
             eng.set_split_gemm(split)
             if not split:
                 # fp32 pipe: the dominant launch is the fused attention-layer tail (out-projection, feed-forward
-                # block, next layer's pre-norm and in-projection); LIGDIFF_NO_CHAIN=1 brings the separate
+                # block, next layer's pre-norm and in-projection); LIGDIFF_CHAIN=0 brings the separate
                 # launches back and the feed-forward up-projection is then the largest one
                 try:
                     eng.time_launch("dit1.chain", graph, x, pos, t_index, reps=2)    # warm

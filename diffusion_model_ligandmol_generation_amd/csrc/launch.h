@@ -26,10 +26,31 @@ static inline bool use_cs() {
   static const bool v = getenv("LIGDIFF_GEMM_NOCS") == nullptr && getenv("LIGDIFF_GEMM_V1") == nullptr;
   return v;
 }
-// Fused chain kernels (ffn_chain.h) on the inference path unless LIGDIFF_NO_CHAIN is set (A/B switch).
-static inline bool use_chain() {
-  static const bool v = use_cs() && getenv("LIGDIFF_NO_CHAIN") == nullptr;
+// Fused chain kernels (*_chain.h) on the inference path.  LIGDIFF_CHAIN in the environment: "0" never
+// (LIGDIFF_NO_CHAIN set means the same), "force" always, otherwise by fill: a chain workgroup (128 rows,
+// one wave per SIMD, > 100 KiB of LDS) has a CU to itself for the whole chain, so a launch of n workgroups
+// takes ceil(n / CUs) rounds whatever n is - half-empty rounds (small batches, or a few rows beyond a
+// multiple of 128 x CUs) are faster on the separate launches, whose column blocks spread over the chip.
+static inline int chain_mode() {   // 0 off, 1 by fill, 2 force
+  static const int v = [] {
+    if (getenv("LIGDIFF_GEMM_NOCS") != nullptr || getenv("LIGDIFF_GEMM_V1") != nullptr || getenv("LIGDIFF_NO_CHAIN") != nullptr) return 0;
+    const char* e = getenv("LIGDIFF_CHAIN");
+    if (e == nullptr || e[0] == '\0') return 1;
+    if (e[0] == '0') return 0;
+    return (e[0] == 'f' || e[0] == 'F') ? 2 : 1;
+  }();
   return v;
+}
+static inline bool use_chain(int64_t rows) {
+  const int mode = chain_mode();
+  if (mode != 1) return mode == 2;
+  static thread_local int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
+  const int64_t n = (rows + 127) / 128, cu = cus[dev] > 0 ? cus[dev] : 256;
+  const int64_t rounds = (n + cu - 1) / cu;
+  return n > 0 && 4 * n >= 3 * rounds * cu;   // last round included, at least three quarters of the slots are used
 }
 // Split-operand mode (gemm4.h): while a cache is installed for the calling thread, the column-split
 // launches below convert each weight block they meet for the first time (one small launch on the

@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_chain.py: runs a fixed set of forwards and one short DDPM sampling call on cuda:0
-and writes the results to the .npz path given as argv[1].  The fused chain kernels are on unless
-LIGDIFF_NO_CHAIN is set in the environment (the library reads the switch once per process)."""
+and writes the results to the .npz path given as argv[1].  LIGDIFF_CHAIN in the environment
+selects the fused chain kernels ("force"), the separate launches ("0") or the by-fill default; the library reads it once per process."""
 import os
 import sys
 

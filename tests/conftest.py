@@ -5,6 +5,11 @@ import numpy as np
 import pytest
 import torch
 
+# The library picks the fused chain kernels of the inference path by how well a launch fills the chip
+# (small batches run the separate GEMM launches).  The GPU parity tests are small on purpose, so they ask
+# for the fused kernels at every size; tests/test_gpu_chain.py compares the two paths directly.
+os.environ.setdefault("LIGDIFF_CHAIN", "force")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,6 +1,7 @@
 """The fused chain kernels of the inference path (ffn / edge / node / attention-layer tail, csrc/*_chain.h)
 against the separate-launch kernels they replace: the same forwards and one sampling call in two processes,
-one with LIGDIFF_NO_CHAIN=1.  Both paths are pinned to the reference by the other GPU tests (each runs with
+one with LIGDIFF_CHAIN=force, one with LIGDIFF_CHAIN=0 (and a third in the default by-fill mode, which must pick the
+separate launches at these sizes bit for bit).  Both paths are pinned to the reference by the other GPU tests (each runs with
 the default, fused, path); this one compares them directly, at shapes that exercise partial workgroups,
 one-atom-short tiles, per-molecule timesteps, property conditioning and fully connected edges."""
 import os
@@ -18,6 +19,7 @@ def _run(tmp_path, name, extra_env):
     out = str(tmp_path / f"{name}.npz")
     env = dict(os.environ)
     env.pop("LIGDIFF_NO_CHAIN", None)
+    env.pop("LIGDIFF_CHAIN", None)
     env.update(extra_env)
     r = subprocess.run([sys.executable, os.path.join(HERE, "_chain_ab.py"), out], env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -25,8 +27,11 @@ def _run(tmp_path, name, extra_env):
 
 
 def test_chain_kernels_match_separate_launches(tmp_path):
-    fused = _run(tmp_path, "fused", {})
-    plain = _run(tmp_path, "plain", {"LIGDIFF_NO_CHAIN": "1"})
+    fused = _run(tmp_path, "fused", {"LIGDIFF_CHAIN": "force"})
+    plain = _run(tmp_path, "plain", {"LIGDIFF_CHAIN": "0"})
+    auto = _run(tmp_path, "auto", {})   # by fill: these batches are far too small for the fused kernels
+    for k in plain.files:
+        assert np.array_equal(auto[k], plain[k]), k
     assert set(fused.files) == set(plain.files)
     for k in fused.files:
         a, b = fused[k], plain[k]

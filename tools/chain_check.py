@@ -1,5 +1,5 @@
 """Forward error against the CPU oracle on the ragged / fully connected test batches, for A/B runs of the
-fused chain kernels (LIGDIFF_NO_CHAIN=1 selects the separate launches).  Usage: python tools/chain_check.py"""
+fused chain kernels (LIGDIFF_CHAIN=force / 0 selects the fused kernels / the separate launches).  Usage: python tools/chain_check.py"""
 import copy
 import os
 import sys
