@@ -41,7 +41,7 @@ struct DitChainArgs {
 
 // GELU (erf form) of an accumulator tile, two elements per packed instruction: with t = |x| and
 // p = sum_k c_k t^k (c_k = a_k 2^(-k/2) 2^(1/16), a_k of Abramowitz-Stegun 7.1.28),
-//   GELU(x) = max(x, 0) - |x| / (2 (1 + a1 t/sqrt2 + ...)^16) = max(x, 0) - |x| p^-16.   |error| <= 8e-7
+//   GELU(x) = max(x, 0) - |x| / (2 (1 + a1 t/sqrt2 + ...)^16) = x / 2 + |x| (1/2 - p^-16).   |error| <= 8e-7
 __device__ __forceinline__ void gelu_tile(f32x16& u) {
 #pragma unroll
   for (int k = 0; k < 16; k += 2) {
@@ -55,9 +55,9 @@ __device__ __forceinline__ void gelu_tile(f32x16& u) {
     p = p * t + 1.0442737340927124f;
     p = p * p; p = p * p; p = p * p; p = p * p;
     const f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
-    const f32x2 tr = t * r;
-    u[k] = fmaxf(x[0], 0.f) - tr[0];
-    u[k + 1] = fmaxf(x[1], 0.f) - tr[1];
+    // max(x, 0) - t r = x / 2 + t (1/2 - r): two packed instructions instead of a multiply, two max and two subtracts
+    const f32x2 y = x * 0.5f + t * (0.5f - r);
+    u[k] = y[0]; u[k + 1] = y[1];
   }
 }
 

@@ -421,11 +421,14 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   // --- E(3) message-passing layers (model1.py:721-725, :86-114)
   const float* h_in = F(L.h0);
   // inference on the fp32 pipe: the three edge launches of a layer run as one fused kernel
-  const bool edge_chain = use_chain(E) && !L.save && g_split == nullptr && E > 0 && (int64_t)N * 512 < (1LL << 31);
+  // (their vector loads and LDS-DMAs need 16-byte aligned weight tensors)
+  bool w_aligned = true;
+  for (int i = 0; i < W_CONS_0; ++i) w_aligned = w_aligned && (w[i] == nullptr || (reinterpret_cast<uintptr_t>(w[i]) & 15) == 0);
+  const bool edge_chain = w_aligned && use_chain(E) && !L.save && g_split == nullptr && E > 0 && (int64_t)N * 512 < (1LL << 31);
   // likewise the node update of a layer together with what follows it (the next layer's per-node edge
   // projections, or the first attention layer's pre-norm and in-projection), and everything between two
   // attention kernels (out-projection, feed-forward block, the next layer's pre-norm and in-projection)
-  const bool node_chain = use_chain(N) && !L.save && g_split == nullptr && N > 0;
+  const bool node_chain = w_aligned && use_chain(N) && !L.save && g_split == nullptr && N > 0;
   const bool dit_chain = node_chain && drop == nullptr;
   for (int l = 0; l < 3; ++l) {
     const float* pos_l = (l == 0) ? pos : F(L.pos_cur);
@@ -666,7 +669,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     if ((dh.thr != 0u || dout.thr != 0u) && !use_cs()) return LIGDIFF_ERR_ARG;
     // inference on the fp32 pipe: the whole feed-forward block as one launch (the [N,1024] hidden
     // activations stay in registers); the next layer's pre-norm is fused as in the two-launch form
-    const bool chain = use_chain(N) && !L.save && dh.thr == 0u && dout.thr == 0u && g_split == nullptr && N > 0;
+    const bool chain = w_aligned && use_chain(N) && !L.save && dh.thr == 0u && dout.thr == 0u && g_split == nullptr && N > 0;
     if (chain) {
       FfnChainArgs fa;
       memset(&fa, 0, sizeof fa);

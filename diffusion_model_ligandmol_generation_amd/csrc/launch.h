@@ -41,14 +41,17 @@ static inline int chain_mode() {   // 0 off, 1 by fill, 2 force
   }();
   return v;
 }
+static inline int device_cus() {   // compute units of the current device
+  static thread_local int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
+  return cus[dev] > 0 ? cus[dev] : 256;
+}
 static inline bool use_chain(int64_t rows) {
   const int mode = chain_mode();
   if (mode != 1) return mode == 2;
-  static thread_local int cus[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
-  const int64_t n = (rows + 127) / 128, cu = cus[dev] > 0 ? cus[dev] : 256;
+  const int64_t n = (rows + 127) / 128, cu = device_cus();
   const int64_t rounds = (n + cu - 1) / cu;
   return n > 0 && 4 * n >= 3 * rounds * cu;   // last round included, at least three quarters of the slots are used
 }
