@@ -105,7 +105,9 @@ struct ChainLane {
 struct NoHook {
   template <class T> __device__ __forceinline__ void operator()(T) const {}
 };
-template <int N, class Rd, class GetB, class GetAcc, class Hook = NoHook>
+// SWAP exchanges the operand roles (A = the register values, B = the LDS fragment): the accumulator tile is
+// then [32 rows x 32 weight rows], rows in the registers and the weight row (output feature) on the lane.
+template <int N, bool SWAP = false, class Rd, class GetB, class GetAcc, class Hook = NoHook>
 __device__ __forceinline__ void chain_groups(Rd&& rd, GetB&& getb, GetAcc&& getacc, Hook&& hook = NoHook{}) {
   f32x4 a[4];
   static_for<0, (N < 3 ? N : 3)>([&](auto J) { a[decltype(J)::value & 3] = rd(J); });
@@ -117,7 +119,9 @@ __device__ __forceinline__ void chain_groups(Rd&& rd, GetB&& getb, GetAcc&& geta
     const f32x4 b = getb(I);
     f32x16& acc = getacc(I);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i & 3][e], b[e], acc, 0, 0, 0);
+    for (int e = 0; e < 4; ++e)
+      acc = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[e], a[i & 3][e], acc, 0, 0, 0)
+                 : __builtin_amdgcn_mfma_f32_32x32x2f32(a[i & 3][e], b[e], acc, 0, 0, 0);
     hook(I);
     __builtin_amdgcn_sched_barrier(0);
   });

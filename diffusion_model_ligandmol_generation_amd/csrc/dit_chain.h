@@ -9,6 +9,12 @@
 // (written behind the first feed-forward step, read back behind the last), the [M,1024] hidden
 // activations, xn2 and the next layer's pre-norm never leave the registers (layout: chain.h).
 //
+// MOLWAVE form (molecules of at most 32 atoms): wave w of workgroup b owns molecule 4b + w instead of 32 consecutive
+// rows, and the kernel STARTS with the layer's own pre-norm, in-projection and attention, head by head - q and k tiles in
+// the transposed layout, the v tile with the operand roles swapped (keys in the registers, head dimension on the lane),
+// so that S^T = K Q^T and O^T = V^T P^T take both operands straight from accumulator registers and the probability
+// tile never moves: no attention launch, no qkv in memory (24 more ring steps in front, no DIT_TAIL_QKV).
+//
 // One workgroup = 4 waves = 128 atoms.  Weight tiles go through a ring of four 32-KiB LDS buffers, tile
 // s in buffer s & 3, fetched two steps ahead behind the MFMAs of step s - 2:
 //   s = 0..7          WIDE tiles of Wo          (out-projection, one output tile each)
@@ -36,6 +42,8 @@ struct DitChainArgs {
   const float* pos_upd;   // [M,3] accumulated coordinate updates of the E(3) layers
   float* atom_pred;       // [M,119]
   float* pos_pred;        // [M,3]
+  // MOLWAVE: this layer's in-projection and the molecule boundaries
+  const float* Wqkv_self; const float* bqkv_self; const int32_t* mol_ptr; int B;
   unsigned long long* stamps;   // diagnostic builds (DBG): [grid][8] shader-clock stamps of wave 0
 };
 
@@ -66,36 +74,54 @@ __device__ __forceinline__ void gelu_tile(f32x16& u) {
 #define DC_VEC_BO 2048
 #define DC_VEC_B2 2304
 #define DC_VEC_B1 2560      // 1024
-#define DC_VEC_BQKV 3584    // 768 (DIT_TAIL_QKV); DIT_TAIL_HEADS puts its vectors here:
-#define DC_VEC_HB0 3584     //   [2][256] hidden bias (atom, pos)
-#define DC_VEC_HG 4096      //   [2][256] LayerNorm weight
-#define DC_VEC_HBE 4608     //   [2][256] LayerNorm bias
-#define DC_VEC_B3A 5120     //   128: atom head output bias (119 valid)
-#define DC_VEC_W3P 5248     //   [3][256] coordinate head output weight
-#define DC_VEC_FL 6016
+#define DC_VEC_BQKV 3584    // 768: in-projection bias (the next layer's for DIT_TAIL_QKV, this layer's for MOLWAVE)
+#define DC_VEC_HB0 4352     // DIT_TAIL_HEADS: [2][256] hidden bias (atom, pos)
+#define DC_VEC_HG 4864      //   [2][256] LayerNorm weight
+#define DC_VEC_HBE 5376     //   [2][256] LayerNorm bias
+#define DC_VEC_B3A 5888     //   128: atom head output bias (119 valid)
+#define DC_VEC_W3P 6016     //   [3][256] coordinate head output weight
+#define DC_VEC_FL 6784
 enum { DIT_TAIL_NONE = 0, DIT_TAIL_QKV = 1, DIT_TAIL_HEADS = 2 };
 
-template <bool SHARED, int TAIL, bool DBG = false>   // SHARED: mod_stride == 0 (one adaLN row set for all molecules)
+template <bool SHARED, int TAIL, bool MOLWAVE = false, bool DBG = false>   // SHARED: mod_stride == 0 (one adaLN row set for all molecules)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void dit_chain_kernel(DitChainArgs p) {
   constexpr bool TAIL_QKV = TAIL == DIT_TAIL_QKV;
+  static_assert(!(MOLWAVE && TAIL_QKV), "the molecule-per-wave form computes its own in-projection");
+  constexpr int SA = MOLWAVE ? 24 : 0;   // ring steps of the attention front
   __shared__ __attribute__((aligned(1024))) float smem[4 * CH_TILE_FL + DC_VEC_FL];
   float* const vec = smem + 4 * CH_TILE_FL;
   const int tid = threadIdx.x;
   ChainLane cl;
   cl.init(smem, tid);
   const int fi = cl.fi, h = cl.h;
-  const int row = blockIdx.x * 128 + cl.wave * 32 + fi;
-  const int rr = row < p.M ? row : p.M - 1;
+  int rr, n_mol = 32;
+  bool valid;
+  if (MOLWAVE) {
+    const int mol = blockIdx.x * 4 + cl.wave;
+    const int mc = mol < p.B ? mol : p.B - 1;
+    const int a0 = p.mol_ptr[mc];
+    n_mol = p.mol_ptr[mc + 1] - a0;
+    rr = a0 + (fi < n_mol ? fi : n_mol - 1);
+    valid = mol < p.B && fi < n_mol;
+  } else {
+    const int row = blockIdx.x * 128 + cl.wave * 32 + fi;
+    rr = row < p.M ? row : p.M - 1;
+    valid = row < p.M;
+  }
   auto stamp = [&](int k) {
     if (DBG && tid == 0) p.stamps[blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
 
   // piece n of ring tile s (uniform s)
-  auto fetch = [&](int s, int n) {
-    float* buf = smem + (s & 3) * CH_TILE_FL;
-    if (s < 8) cl.dma_wide(p.Wo, 256, 32 * s, 256, 0, buf, n);
+  auto fetch = [&](int sa, int n) {
+    float* buf = smem + (sa & 3) * CH_TILE_FL;
+    const int s = sa - SA;
+    if (MOLWAVE && s < 0) {   // attention front: head sa / 3, q / k / v rows of this layer's in-projection
+      const int hd = sa / 3, kind = sa - 3 * hd;
+      cl.dma_wide(p.Wqkv_self, 256, 256 * kind + 32 * hd, 768, 0, buf, n);
+    } else if (s < 8) cl.dma_wide(p.Wo, 256, 32 * s, 256, 0, buf, n);
     else if (s < 72) {
       const int t = (s - 8) >> 1;
       if (s & 1) cl.dma_tall(p.W2, 1024, 32 * t, buf, n);
@@ -107,13 +133,13 @@ void dit_chain_kernel(DitChainArgs p) {
       else cl.dma_wide(p.W0p, 256, 32 * (s - 84), 256, 0, buf, n);
     }
   };
-  constexpr int S_END = TAIL_QKV ? 96 : TAIL == DIT_TAIL_HEADS ? 92 : 72;
+  constexpr int S_END = SA + (TAIL_QKV ? 96 : TAIL == DIT_TAIL_HEADS ? 92 : 72);   // ring steps s + SA below
 #pragma unroll
   for (int n = 0; n < 8; ++n) { fetch(0, n); fetch(1, n); }
 
   // small vectors -> LDS (all loads first, then the writes)
   {
-    constexpr int NV = TAIL == DIT_TAIL_HEADS ? 896 : 1088;   // float4 slots
+    constexpr int NV = 1088;   // float4 slots
     f32x4 v[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -124,7 +150,7 @@ void dit_chain_kernel(DitChainArgs p) {
       else if (idx < 576) src = p.bo + (idx - 512) * 4;
       else if (idx < 640) src = p.b2 + (idx - 576) * 4;
       else if (idx < 896) src = p.b1 + (idx - 640) * 4;
-      else if (idx < 1088) src = TAIL_QKV ? p.bqkv + (idx - 896) * 4 : nullptr;
+      else if (idx < 1088) src = TAIL_QKV ? p.bqkv + (idx - 896) * 4 : MOLWAVE ? p.bqkv_self + (idx - 896) * 4 : nullptr;
       v[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -134,7 +160,7 @@ void dit_chain_kernel(DitChainArgs p) {
     }
   }
 
-  if (TAIL == DIT_TAIL_HEADS) {   // the heads' vectors (float4 slots 896 ..): 128 x 6 hidden-layer vectors, 32 b3a, 192 W3p
+  if (TAIL == DIT_TAIL_HEADS) {   // the heads' vectors (float4 slots 1088 ..): 128 x 6 hidden-layer vectors, 32 b3a, 192 W3p
     f32x4 v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -207,7 +233,7 @@ void dit_chain_kernel(DitChainArgs p) {
         [&](auto) -> f32x16& { return acc; },
         [&](auto J) {
           constexpr int j = decltype(J)::value;
-          if (j >= 8 && j < 16 && s + 2 < S_END) fetch(s + 2, j - 8);
+          if (j >= 8 && j < 16 && s + SA + 2 < S_END) fetch(s + SA + 2, j - 8);
           extra(J);
         });
   };
@@ -223,7 +249,7 @@ void dit_chain_kernel(DitChainArgs p) {
         [&](auto J) -> f32x16& { return out[decltype(J)::value >> 2]; },
         [&](auto J) {
           constexpr int j = decltype(J)::value;
-          if (j >= 8 && j < 16 && s + 2 < S_END) fetch(s + 2, j - 8);
+          if (j >= 8 && j < 16 && s + SA + 2 < S_END) fetch(s + SA + 2, j - 8);
           extra(J);
         });
   };
@@ -260,19 +286,92 @@ void dit_chain_kernel(DitChainArgs p) {
       }
   };
 
-  // ---- out-projection: att slab -> x1
-  f32x16 xs[8];   // the current B slab: att, then xn2, then the next layer's pre-norm
-  {
-    const float* arow = p.att + (size_t)rr * 256 + 4 * h;
+  f32x16 xs[8];   // the current B slab: (pre-norm,) att, then xn2, then the next layer's pre-norm
+  f32x16 x1[8];
+  auto load_rows = [&](f32x16 (&dst)[8], const float* base) {
+    const float* r = base + (size_t)rr * 256 + 4 * h;
 #pragma unroll
     for (int m = 0; m < 32; ++m) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 8 * m);
-      xs[m >> 2][4 * (m & 3)] = a[0]; xs[m >> 2][4 * (m & 3) + 1] = a[1]; xs[m >> 2][4 * (m & 3) + 2] = a[2]; xs[m >> 2][4 * (m & 3) + 3] = a[3];
+      const f32x4 a = *reinterpret_cast<const f32x4*>(r + 8 * m);
+      dst[m >> 2][4 * (m & 3)] = a[0]; dst[m >> 2][4 * (m & 3) + 1] = a[1]; dst[m >> 2][4 * (m & 3) + 2] = a[2]; dst[m >> 2][4 * (m & 3) + 3] = a[3];
     }
+  };
+  if constexpr (!MOLWAVE) {
+    load_rows(xs, p.att);
+    open_step();   // ring tiles 0, 1 and the small vectors are in LDS
+  } else {
+    // ---- attention front: pre-norm of the wave's molecule, then per head q / k / v tiles (ring steps 3 hd ..),
+    // S^T = K Q^T, softmax over the molecule's keys, O^T = V^T P^T
+    f32x16 xn[8];
+    load_rows(x1, p.x);
+    open_step();
+    ln_mod(x1, xn, [&](int m) { return modv(256, m); }, [&](int m) { return modv(0, m); });
+    auto front_step = [&](auto S, f32x16& acc, auto SW) {   // ring step S over the pre-norm slab
+      constexpr int s0 = decltype(S)::value, bf = s0 & 3;
+      constexpr bool swap = decltype(SW)::value;
+      chain_groups<32, swap>(
+          [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if constexpr (bf < 2) return lds_read128<(j >> 3) * 256 + bf * CH_TILE_FL * 4>(cl.a_wide[j & 7]);
+            else return lds_read128<(j >> 3) * 256 + (bf - 2) * CH_TILE_FL * 4>(aw2[j & 7]);
+          },
+          [&](auto J) {
+            constexpr int m = decltype(J)::value;
+            return f32x4{xn[m >> 2][4 * (m & 3)], xn[m >> 2][4 * (m & 3) + 1], xn[m >> 2][4 * (m & 3) + 2], xn[m >> 2][4 * (m & 3) + 3]};
+          },
+          [&](auto) -> f32x16& { return acc; },
+          [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            if (j >= 8 && j < 16) fetch(s0 + 2, j - 8);
+          });
+    };
+    static_for<0, 8>([&](auto HD) {
+      constexpr int hd = decltype(HD)::value;
+      f32x16 qt, kt, vt;
+      if (hd > 0) open_step(!((3 * hd) & 1));
+      init_tile(qt, DC_VEC_BQKV, hd);
+      front_step(std::integral_constant<int, 3 * hd>{}, qt, std::false_type{});
+      open_step(!((3 * hd + 1) & 1));
+      init_tile(kt, DC_VEC_BQKV, 8 + hd);
+      front_step(std::integral_constant<int, 3 * hd + 1>{}, kt, std::false_type{});
+      open_step(!((3 * hd + 2) & 1));
+      {   // v tile with the roles swapped: keys in the registers, head dimension (and its bias) on the lane
+        const float bv = vec[DC_VEC_BQKV + 512 + 32 * hd + fi];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vt[r] = bv;
+      }
+      front_step(std::integral_constant<int, 3 * hd + 2>{}, vt, std::true_type{});
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[r], qt[r], st, 0, 0, 0);
+      // lane = query; register 4g + q of lane half h = key 8g + 4h + q
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 8 * (r >> 2) + 4 * h + (r & 3);
+        st[r] = key < n_mol ? st[r] * 0.17677669529663687f : -INFINITY;
+        mx = fmaxf(mx, st[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = __expf(st[r] - mx); sum += st[r]; }
+      sum += __shfl_xor(sum, 32);
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] *= inv;
+      f32x16 ot;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot = __builtin_amdgcn_mfma_f32_32x32x2f32(vt[r], st[r], ot, 0, 0, 0);
+      xs[hd] = ot;
+    });
+    open_step(true);   // (SA = 24 is even: the first out-projection step opens with a barrier)
   }
-  open_step();   // ring tiles 0, 1 and the small vectors are in LDS
   stamp(1);
-  f32x16 x1[8];
   static_for<0, 8>([&](auto O) {
     constexpr int o = decltype(O)::value;
     if (o > 0) open_step(!(o & 1));
@@ -298,7 +397,7 @@ void dit_chain_kernel(DitChainArgs p) {
   f32x16 out[8];
   auto store_x1 = [&](auto J) {   // behind the first feed-forward step: x1 -> HBM, one 16-byte piece per group
     constexpr int j = decltype(J)::value;
-    if (row < p.M)
+    if (valid)
       *reinterpret_cast<f32x4*>(xrow_out + 8 * j) =
           f32x4{x1[j >> 2][4 * (j & 3)], x1[j >> 2][4 * (j & 3) + 1], x1[j >> 2][4 * (j & 3) + 2], x1[j >> 2][4 * (j & 3) + 3]};
   };
@@ -344,7 +443,7 @@ void dit_chain_kernel(DitChainArgs p) {
   }
   auto store_x2 = [&](auto J) {
     constexpr int j = decltype(J)::value;
-    if (row < p.M)
+    if (valid)
       *reinterpret_cast<f32x4*>(xrow_out + 8 * j) =
           f32x4{x1[j >> 2][4 * (j & 3)], x1[j >> 2][4 * (j & 3) + 1], x1[j >> 2][4 * (j & 3) + 2], x1[j >> 2][4 * (j & 3) + 3]};
   };
@@ -397,7 +496,7 @@ void dit_chain_kernel(DitChainArgs p) {
         open_step(!(q & 1));
         init_tile(acc, DC_VEC_B3A, q);
         wide_step(std::integral_constant<int, (80 + q) & 3>{}, 80 + q, acc, yh, NoHook{});
-        if (row < p.M) {
+        if (valid) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -420,9 +519,9 @@ void dit_chain_kernel(DitChainArgs p) {
         }
 #pragma unroll
       for (int o = 0; o < 3; ++o) d[o] += __shfl_xor(d[o], 32);
-      if (h == 0 && row < p.M) {
+      if (h == 0 && valid) {
 #pragma unroll
-        for (int o = 0; o < 3; ++o) p.pos_pred[(size_t)row * 3 + o] = d[o] + p.b3p[o] + p.pos_upd[(size_t)row * 3 + o];
+        for (int o = 0; o < 3; ++o) p.pos_pred[(size_t)rr * 3 + o] = d[o] + p.b3p[o] + p.pos_upd[(size_t)rr * 3 + o];
       }
     }
     return;
@@ -435,7 +534,7 @@ void dit_chain_kernel(DitChainArgs p) {
   f32x16 qa, qb;
   auto store_q = [&](f32x16& a, int tile, auto J) {   // 4 pieces of output tile `tile`, behind groups 0..3
     constexpr int j = decltype(J)::value;
-    if (j < 4 && row < p.M)
+    if (j < 4 && valid)
       *reinterpret_cast<f32x4*>(qrow + 32 * tile + 8 * j) = f32x4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
   };
   auto qkv_quad = [&](int q, auto FIRST) {

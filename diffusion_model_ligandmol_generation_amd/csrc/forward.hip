@@ -430,6 +430,10 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   // attention kernels (out-projection, feed-forward block, the next layer's pre-norm and in-projection)
   const bool node_chain = w_aligned && use_chain(N) && !L.save && g_split == nullptr && N > 0;
   const bool dit_chain = node_chain && drop == nullptr;
+  // molecules of at most 32 atoms that fill at least three quarters of a 32-lane slab each: one molecule per wave,
+  // attention inside the attention-layer kernel (no attention launches, no qkv in memory)
+  const bool mol_wave = dit_chain && chain_mol_allowed() && g->max_mol_atoms <= 32 && 4 * (int64_t)N >= 3 * 32 * (int64_t)B &&
+                        use_chain(32 * (int64_t)B);
   for (int l = 0; l < 3; ++l) {
     const float* pos_l = (l == 0) ? pos : F(L.pos_cur);
     // per-node halves of the first edge linear: P = h [W1a | W1b]^T
@@ -527,7 +531,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       if (l < 2) {
         na.Wt = w[W_E3(l + 1, E3_EN0_W)]; na.bt = edge_chain ? w[W_E3(l + 1, E3_EN0_B)] : nullptr; na.tout = F(L.P[l + 1]);
         hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_PROJ, true>), grid, dim3(256), 0, s, na);
-      } else if (dit_chain) {
+      } else if (dit_chain && !mol_wave) {
         na.Wt = w[W_DIT(0, DIT_INP_W)]; na.bt = w[W_DIT(0, DIT_INP_B)]; na.tout = F(L.qkv[0]);
         na.mod = F(L.mod[0]); na.mod_stride = mstride; na.atom_mol = g->atom_mol;
         if (mstride == 0) hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_QKV, true>), grid, dim3(256), 0, s, na);
@@ -586,6 +590,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
                                      F(L.qkv[l]), 768, nullptr, s);
       PE();
     }
+    if (!mol_wave) {
     PB("dit%d.attention", l);
     {
       const int tk = (max_n + 31) / 32;
@@ -624,6 +629,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         hipLaunchKernelGGL(k_attention_mfma<4>, dim3(blocks), dim3(256), lds, s, F(L.qkv[l]), g->mol_ptr, F(L.att[l]), S(L.lse[l]), B);
     }
     PE();
+    }
     if (dit_chain) {
       DitChainArgs da;
       memset(&da, 0, sizeof da);
@@ -635,7 +641,11 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         da.mod_next = F(L.mod[l + 1]); da.Wqkv = w[W_DIT(l + 1, DIT_INP_W)]; da.bqkv = w[W_DIT(l + 1, DIT_INP_B)];
         da.qkv = F(L.qkv[l + 1]);
       }
-      const dim3 grid(ceil_div(N, 128));
+      const dim3 grid(mol_wave ? ceil_div(B, 4) : ceil_div(N, 128));
+      if (mol_wave) {
+        da.Wqkv_self = w[W_DIT(l, DIT_INP_W)]; da.bqkv_self = w[W_DIT(l, DIT_INP_B)]; da.mol_ptr = g->mol_ptr; da.B = B;
+        da.Wqkv = nullptr; da.bqkv = nullptr; da.qkv = nullptr; da.mod_next = nullptr;
+      }
       PB("dit%d.chain", l);
       if (l == 2) {   // the last layer carries the atom and coordinate heads (model1.py:741-742)
         da.W0a = w[W_HEAD(0, HEAD_W0)]; da.b0a = w[W_HEAD(0, HEAD_B0)]; da.ga = w[W_HEAD(0, HEAD_G)]; da.bea = w[W_HEAD(0, HEAD_BE)];
@@ -644,7 +654,15 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         da.W3p = w[W_HEAD(1, HEAD_W3)]; da.b3p = w[W_HEAD(1, HEAD_B3)];
         da.pos_upd = F(L.pos_upd); da.atom_pred = atom_pred; da.pos_pred = pos_pred;
       }
-      if (mstride == 0) {
+      if (mol_wave) {
+        if (mstride == 0) {
+          if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_NONE, true>), grid, dim3(256), 0, s, da);
+          else hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_HEADS, true>), grid, dim3(256), 0, s, da);
+        } else {
+          if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<false, DIT_TAIL_NONE, true>), grid, dim3(256), 0, s, da);
+          else hipLaunchKernelGGL((dit_chain_kernel<false, DIT_TAIL_HEADS, true>), grid, dim3(256), 0, s, da);
+        }
+      } else if (mstride == 0) {
         if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_QKV>), grid, dim3(256), 0, s, da);
         else hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_HEADS>), grid, dim3(256), 0, s, da);
       } else {

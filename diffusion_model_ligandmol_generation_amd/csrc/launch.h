@@ -41,6 +41,11 @@ static inline int chain_mode() {   // 0 off, 1 by fill, 2 force
   }();
   return v;
 }
+// Molecule-per-wave form of the attention-layer kernel (attention inside it) unless LIGDIFF_CHAIN_MOL=0 (A/B switch).
+static inline bool chain_mol_allowed() {
+  static const bool v = [] { const char* e = getenv("LIGDIFF_CHAIN_MOL"); return !(e != nullptr && e[0] == '0'); }();
+  return v;
+}
 static inline int device_cus() {   // compute units of the current device
   static thread_local int cus[64];
   int dev = 0;

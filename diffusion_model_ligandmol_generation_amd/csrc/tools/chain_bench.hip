@@ -274,7 +274,7 @@ static void dit_test(int M, int stride) {
   const float d2 = max_diff(QA, QB, (size_t)M * 768, &m2);
   printf("attention-layer tail M=%d mod_stride=%d: max |x2 diff| %.3e (max |x2| %.3f)  max |qkv diff| %.3e (max %.3f)\n", M, stride, d1, m1, d2, m2);
   if (stride == 0) {
-    hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_QKV, true>), dim3(nblk), dim3(256), 0, 0, da);
+    hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_QKV, false, true>), dim3(nblk), dim3(256), 0, 0, da);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st((size_t)nblk * 8);
     CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
