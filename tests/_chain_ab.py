@@ -54,7 +54,7 @@ def main(out_path):
                 a, q, r, _ = model(d, t.cuda())
         out[f"c{ci}_atom"] = a.cpu().numpy(); out[f"c{ci}_pos"] = q.cpu().numpy(); out[f"c{ci}_prop"] = r.cpu().numpy()
     gen = ResearchValidatedGenerator(model)
-    xs, ps, _, _ = gen.sample_batch([9, 12, 29, 30, 33], None, 1.0, 1.0, num_steps=25, seed=7)
+    xs, ps, _, _ = gen.sample_batch([25, 29, 30, 32, 27], None, 1.0, 1.0, num_steps=25, seed=7)   # molecule-per-wave form when allowed
     out["s_x"] = xs.cpu().numpy(); out["s_pos"] = ps.cpu().numpy()
     np.savez(out_path, **out)
 

@@ -29,15 +29,22 @@ def _run(tmp_path, name, extra_env):
 def test_chain_kernels_match_separate_launches(tmp_path):
     fused = _run(tmp_path, "fused", {"LIGDIFF_CHAIN": "force"})
     plain = _run(tmp_path, "plain", {"LIGDIFF_CHAIN": "0"})
+    rows = _run(tmp_path, "rows", {"LIGDIFF_CHAIN": "force", "LIGDIFF_CHAIN_MOL": "0"})   # attention as its own launch
     auto = _run(tmp_path, "auto", {})   # by fill: these batches are far too small for the fused kernels
     for k in plain.files:
         assert np.array_equal(auto[k], plain[k]), k
     assert set(fused.files) == set(plain.files)
+    # case 0 (40 x 29 atoms) takes the molecule-per-wave form of the attention-layer kernel when it is allowed
+    assert not np.array_equal(fused["c0_atom"], rows["c0_atom"])
     for k in fused.files:
-        a, b = fused[k], plain[k]
-        assert a.shape == b.shape and np.isfinite(a).all() and np.isfinite(b).all(), k
-        # fp32 summation orders differ between the two paths: tolerance relative to the tensor's scale
-        # (the sampled state after 25 reverse steps accumulates 25 forwards' worth of it)
-        scale = max(1.0, float(np.abs(b).max()))
-        tol = (2e-4 if k.startswith("s_") else 2e-5) * scale
-        assert float(np.abs(a - b).max()) <= tol, (k, float(np.abs(a - b).max()), scale)
+        if not k.startswith("c0_") and not k.startswith("s_"):
+            assert np.array_equal(fused[k], rows[k]), k
+    for name, other in (("plain", plain), ("rows", rows)):
+        for k in fused.files:
+            a, b = fused[k], other[k]
+            assert a.shape == b.shape and np.isfinite(a).all() and np.isfinite(b).all(), (name, k)
+            # fp32 summation orders differ between the paths: tolerance relative to the tensor's scale
+            # (the sampled state after 25 reverse steps accumulates 25 forwards' worth of it)
+            scale = max(1.0, float(np.abs(b).max()))
+            tol = (2e-4 if k.startswith("s_") else 2e-5) * scale
+            assert float(np.abs(a - b).max()) <= tol, (name, k, float(np.abs(a - b).max()), scale)
