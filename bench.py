@@ -462,14 +462,26 @@ def run_rank(args):
                     eng.time_launch("dit1.chain", graph, x, pos, t_index, reps=2)    # warm
                     ms = eng.time_launch("dit1.chain", graph, x, pos, t_index, reps=10)
                     eng.set_split_gemm(split_mode)
+                    # 29-atom ligands take the molecule-per-wave form: the layer's own in-projection and attention
+                    # (8 heads x (K Q^T + V^T P^T) on 32 x 32 x 32 tiles per molecule) sit in front of the out-projection
+                    mol_form = ATOMS <= 32 and os.environ.get("LIGDIFF_CHAIN_MOL", "1")[:1] != "0"
                     flops = 2.0 * N * (256 * 256 + 2 * 256 * 1024 + 256 * 768)
+                    if mol_form:
+                        flops += MOLS_PER_GPU * 8 * 2 * 2.0 * 32 * 32 * 32
+                        name = ("dit_chain_kernel<true, DIT_TAIL_NONE, MOLWAVE> (dit*.chain: pre-norm, in-projection 256-768, "
+                                "attention over the molecule, out-projection + gated residual + LN, FFN 256-1024-256 with GELU, "
+                                f"gated residual; one molecule per wave, M={N})")
+                        needle = "dit_chain_kernel<true, 0, true"
+                    else:
+                        name = ("dit_chain_kernel<true, DIT_TAIL_QKV> (dit*.chain: out-projection + gated residual + LN, FFN "
+                                "256-1024-256 with GELU, gated residual + next layer's LN and in-projection 256-768; "
+                                f"M={N})")
+                        needle = "dit_chain_kernel<true, 1, false"
                     ach = flops / (ms * 1e-3) / 1e12
-                    return {"kernel": "dit_chain_kernel<true, true> (dit*.chain: out-projection + gated residual + LN, FFN "
-                                      "256-1024-256 with GELU, gated residual + next layer's LN and in-projection 256-768; "
-                                      f"M={N})",
+                    return {"kernel": name,
                             "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_F32_MFMA_TFLOPS, "flops_per_launch": flops,
-                            "traffic": traffic_of(traffic, "dit_chain_kernel<true, true"),
+                            "traffic": traffic_of(traffic, needle),
                             "traffic_source": traffic_src, "avg_launch_ms": ms}
                 except Exception:   # noqa: BLE001  (label not present: chain kernels switched off)
                     pass
