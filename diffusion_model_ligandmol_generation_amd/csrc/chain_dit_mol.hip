@@ -1,0 +1,16 @@
+// Fused attention layer, molecule-per-wave form (attention inside the kernel): kernel instantiations and
+// the launcher of both forms.
+#include "dit_chain.h"
+
+void launch_dit_chain_row(const DitChainArgs& a, int tail, hipStream_t s);
+
+void launch_dit_chain(const DitChainArgs& a, int tail, bool mol_wave, hipStream_t s) {
+  if (a.M <= 0) return;
+  if (!mol_wave) {
+    launch_dit_chain_row(a, tail, s);
+    return;
+  }
+  const dim3 grid((a.B + 3) / 4);
+  if (tail == DIT_TAIL_HEADS) hipLaunchKernelGGL((dit_chain_kernel<DIT_TAIL_HEADS, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((dit_chain_kernel<DIT_TAIL_NONE, true>), grid, dim3(256), 0, s, a);
+}

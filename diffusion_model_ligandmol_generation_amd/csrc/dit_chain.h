@@ -21,31 +21,12 @@
 //   s = 8 + 2t, 9 + 2t  WIDE tile t of W1, TALL tile t of W2   (t = 0..31)
 //   s = 72 + q        WIDE tiles of Wqkv'       (q = 0..23, DIT_TAIL_QKV)
 //   s = 72..79, 80..83, 84..91   WIDE tiles of W0_atom, W3_atom (rows clamped to 119), W0_pos   (DIT_TAIL_HEADS)
-// The small vectors (adaLN rows when all molecules share the timestep, biases) are staged in LDS once.
+// The small vectors (the adaLN row - the kernels serve calls whose molecules share one timestep - and the biases) are
+// staged in LDS once.
 #pragma once
 #include "chain.h"
+#include "chain_args.h"
 
-struct DitChainArgs {
-  int M;
-  const float* att;     // [M,256] attention output (heads concatenated)
-  const float* x;       // [M,256] residual stream in
-  float* xout;          // [M,256] residual stream out (may be x)
-  const float* Wo; const float* bo;
-  const float* W1; const float* b1; const float* W2; const float* b2;
-  const float* mod; int mod_stride;   // this layer's adaLN rows [B or 1, stride]: shift_msa | scale_msa | gate_msa | shift_mlp | scale_mlp | gate_mlp
-  const float* mod_next;              // the next layer's rows (TAIL_QKV): shift_msa | scale_msa | ...
-  const int32_t* atom_mol;
-  const float* Wqkv; const float* bqkv; float* qkv;   // DIT_TAIL_QKV: next layer's in_proj, output [M,768]
-  // DIT_TAIL_HEADS: hidden layers (Linear 256-256, GELU, LayerNorm) and output layers of the atom / coordinate heads
-  const float* W0a; const float* b0a; const float* ga; const float* bea; const float* W3a; const float* b3a;
-  const float* W0p; const float* b0p; const float* gp; const float* bep; const float* W3p; const float* b3p;
-  const float* pos_upd;   // [M,3] accumulated coordinate updates of the E(3) layers
-  float* atom_pred;       // [M,119]
-  float* pos_pred;        // [M,3]
-  // MOLWAVE: this layer's in-projection and the molecule boundaries
-  const float* Wqkv_self; const float* bqkv_self; const int32_t* mol_ptr; int B;
-  unsigned long long* stamps;   // diagnostic builds (DBG): [grid][8] shader-clock stamps of wave 0
-};
 
 // GELU (erf form) of an accumulator tile, two elements per packed instruction: with t = |x| and
 // p = sum_k c_k t^k (c_k = a_k 2^(-k/2) 2^(1/16), a_k of Abramowitz-Stegun 7.1.28),
@@ -69,7 +50,7 @@ __device__ __forceinline__ void gelu_tile(f32x16& u) {
   }
 }
 
-#define DC_VEC_MOD 0        // 1536 floats: this layer's adaLN rows (shared-timestep form)
+#define DC_VEC_MOD 0        // 1536 floats: this layer's adaLN row
 #define DC_VEC_MODN 1536    // 512: next layer's shift_msa | scale_msa
 #define DC_VEC_BO 2048
 #define DC_VEC_B2 2304
@@ -81,9 +62,8 @@ __device__ __forceinline__ void gelu_tile(f32x16& u) {
 #define DC_VEC_B3A 5888     //   128: atom head output bias (119 valid)
 #define DC_VEC_W3P 6016     //   [3][256] coordinate head output weight
 #define DC_VEC_FL 6784
-enum { DIT_TAIL_NONE = 0, DIT_TAIL_QKV = 1, DIT_TAIL_HEADS = 2 };
 
-template <bool SHARED, int TAIL, bool MOLWAVE = false, bool DBG = false>   // SHARED: mod_stride == 0 (one adaLN row set for all molecules)
+template <int TAIL, bool MOLWAVE = false, bool DBG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void dit_chain_kernel(DitChainArgs p) {
   constexpr bool TAIL_QKV = TAIL == DIT_TAIL_QKV;
@@ -145,8 +125,8 @@ void dit_chain_kernel(DitChainArgs p) {
     for (int i = 0; i < 5; ++i) {
       const int idx = tid + 256 * i;
       const float* src = nullptr;
-      if (idx < 384) src = SHARED ? p.mod + idx * 4 : nullptr;
-      else if (idx < 512) src = (SHARED && TAIL_QKV) ? p.mod_next + (idx - 384) * 4 : nullptr;
+      if (idx < 384) src = p.mod + idx * 4;
+      else if (idx < 512) src = TAIL_QKV ? p.mod_next + (idx - 384) * 4 : nullptr;
       else if (idx < 576) src = p.bo + (idx - 512) * 4;
       else if (idx < 640) src = p.b2 + (idx - 576) * 4;
       else if (idx < 896) src = p.b1 + (idx - 640) * 4;
@@ -186,16 +166,8 @@ void dit_chain_kernel(DitChainArgs p) {
     }
   }
   // adaLN vector `off` (0 shift_msa .. 1280 gate_mlp), features 8m + 4h .. + 3, for this lane's molecule
-  const float* const mrow = SHARED ? nullptr : p.mod + (size_t)p.atom_mol[rr] * p.mod_stride + 4 * h;
-  const float* const mrow_n = (SHARED || !TAIL_QKV) ? nullptr : p.mod_next + (size_t)p.atom_mol[rr] * p.mod_stride + 4 * h;
-  auto modv = [&](int off, int m) -> f32x4 {
-    if (SHARED) return *reinterpret_cast<const f32x4*>(vec + DC_VEC_MOD + off + 8 * m + 4 * h);
-    return *reinterpret_cast<const f32x4*>(mrow + off + 8 * m);
-  };
-  auto modv_next = [&](int off, int m) -> f32x4 {
-    if (SHARED) return *reinterpret_cast<const f32x4*>(vec + DC_VEC_MODN + off + 8 * m + 4 * h);
-    return *reinterpret_cast<const f32x4*>(mrow_n + off + 8 * m);
-  };
+  auto modv = [&](int off, int m) -> f32x4 { return *reinterpret_cast<const f32x4*>(vec + DC_VEC_MOD + off + 8 * m + 4 * h); };
+  auto modv_next = [&](int off, int m) -> f32x4 { return *reinterpret_cast<const f32x4*>(vec + DC_VEC_MODN + off + 8 * m + 4 * h); };
   auto vec4 = [&](int off, int m) -> f32x4 { return *reinterpret_cast<const f32x4*>(vec + off + 8 * m + 4 * h); };
 
   // fragment addresses: buffers 0 / 1 and 2 / 3 share a base each (the odd one sits 32 KiB further, inside

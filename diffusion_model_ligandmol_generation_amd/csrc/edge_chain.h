@@ -11,20 +11,8 @@
 // a ring of three 32-KiB buffers, fetched two steps ahead.
 #pragma once
 #include "chain.h"
+#include "chain_args.h"
 
-struct EdgeChainArgs {
-  int E;
-  const float* rbf;          // [E,32]
-  const float* rel;          // [E,4]
-  const int32_t* src; const int32_t* dst;
-  const float* P;            // [N,512]
-  const float* Wc; int ldwc; // rbf columns of the first edge linear: [256 x 32], leading dimension ldwc
-  const float* W2; const float* b2; const float* gamma; const float* beta;
-  const float* Wc1; const float* bc1; const float* wc2; const float* bc2;
-  float* msg;                // [E,256]
-  float* wrel;               // [E,4] (components 0..2 written)
-  unsigned long long* stamps;   // diagnostic builds (DBG): [grid][8] shader-clock stamps of wave 0
-};
 
 template <bool DBG = false, int ABL = 0>   // ABL: timing ablations (developer switch; results are wrong when non-zero)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))

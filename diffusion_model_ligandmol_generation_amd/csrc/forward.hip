@@ -6,10 +6,7 @@
 
 #include "epilogues.h"
 #include "gemm3.h"
-#include "ffn_chain.h"
-#include "edge_chain.h"
-#include "dit_chain.h"
-#include "node_chain.h"
+#include "chain_args.h"
 #include "forward.h"
 #include "kernels.h"
 #include "weights.h"
@@ -429,7 +426,8 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   // projections, or the first attention layer's pre-norm and in-projection), and everything between two
   // attention kernels (out-projection, feed-forward block, the next layer's pre-norm and in-projection)
   const bool node_chain = w_aligned && use_chain(N) && !L.save && g_split == nullptr && N > 0;
-  const bool dit_chain = node_chain && drop == nullptr;
+  // (the node and attention-layer kernels stage ONE adaLN row: calls whose molecules share the timestep)
+  const bool dit_chain = node_chain && drop == nullptr && mstride == 0;
   // molecules of at most 32 atoms that fill at least three quarters of a 32-lane slab each: one molecule per wave,
   // attention inside the attention-layer kernel (no attention launches, no qkv in memory)
   const bool mol_wave = dit_chain && chain_mol_allowed() && g->max_mol_atoms <= 32 && 4 * (int64_t)N >= 3 * 32 * (int64_t)B &&
@@ -476,7 +474,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         ea.Wc1 = w[W_E3(l, E3_CN0_W)]; ea.bc1 = w[W_E3(l, E3_CN0_B)]; ea.wc2 = w[W_E3(l, E3_CN2_W)]; ea.bc2 = w[W_E3(l, E3_CN2_B)];
         ea.msg = F(L.msg[l]); ea.wrel = F(L.wrel[l]);
         PB("e3_%d.edge_chain", l);
-        hipLaunchKernelGGL((edge_chain_kernel<false, 0>), dim3(ceil_div(E, 128)), dim3(256), 0, s, ea);
+        launch_edge_chain(ea, s);
         PE();
       } else {
       {  // a1 = SiLU(Pa[src] + Pb[dst] + Wc rbf + b1)
@@ -526,18 +524,15 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       na.M = N; na.h = h_in; na.agg = F(L.agg[l]); na.hout = F(L.h_e3[l]);
       na.Wn1 = w[W_E3(l, E3_NN0_W)]; na.b1 = w[W_E3(l, E3_NN0_B)]; na.Wn2 = w[W_E3(l, E3_NN2_W)]; na.b2 = w[W_E3(l, E3_NN2_B)];
       na.gamma = w[W_E3(l, E3_NN3_G)]; na.beta = w[W_E3(l, E3_NN3_B)];
-      const dim3 grid(ceil_div(N, 128));
       PB("e3_%d.node_chain", l);
       if (l < 2) {
         na.Wt = w[W_E3(l + 1, E3_EN0_W)]; na.bt = edge_chain ? w[W_E3(l + 1, E3_EN0_B)] : nullptr; na.tout = F(L.P[l + 1]);
-        hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_PROJ, true>), grid, dim3(256), 0, s, na);
+        launch_node_chain(na, NODE_TAIL_PROJ, s);
       } else if (dit_chain && !mol_wave) {
-        na.Wt = w[W_DIT(0, DIT_INP_W)]; na.bt = w[W_DIT(0, DIT_INP_B)]; na.tout = F(L.qkv[0]);
-        na.mod = F(L.mod[0]); na.mod_stride = mstride; na.atom_mol = g->atom_mol;
-        if (mstride == 0) hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_QKV, true>), grid, dim3(256), 0, s, na);
-        else hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_QKV, false>), grid, dim3(256), 0, s, na);
+        na.Wt = w[W_DIT(0, DIT_INP_W)]; na.bt = w[W_DIT(0, DIT_INP_B)]; na.tout = F(L.qkv[0]); na.mod = F(L.mod[0]);
+        launch_node_chain(na, NODE_TAIL_QKV, s);
       } else {
-        hipLaunchKernelGGL((node_chain_kernel<NODE_TAIL_NONE, true>), grid, dim3(256), 0, s, na);
+        launch_node_chain(na, NODE_TAIL_NONE, s);
       }
       PE();
       h_in = F(L.h_e3[l]);
@@ -636,17 +631,15 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       da.M = N; da.att = F(L.att[l]); da.x = x_in; da.xout = F(L.x2[l]);
       da.Wo = w[W_DIT(l, DIT_OUT_W)]; da.bo = w[W_DIT(l, DIT_OUT_B)];
       da.W1 = w[W_DIT(l, DIT_FF0_W)]; da.b1 = w[W_DIT(l, DIT_FF0_B)]; da.W2 = w[W_DIT(l, DIT_FF3_W)]; da.b2 = w[W_DIT(l, DIT_FF3_B)];
-      da.mod = F(L.mod[l]); da.mod_stride = mstride; da.atom_mol = g->atom_mol;
+      da.mod = F(L.mod[l]);
       if (l < 2) {
         da.mod_next = F(L.mod[l + 1]); da.Wqkv = w[W_DIT(l + 1, DIT_INP_W)]; da.bqkv = w[W_DIT(l + 1, DIT_INP_B)];
         da.qkv = F(L.qkv[l + 1]);
       }
-      const dim3 grid(mol_wave ? ceil_div(B, 4) : ceil_div(N, 128));
       if (mol_wave) {
         da.Wqkv_self = w[W_DIT(l, DIT_INP_W)]; da.bqkv_self = w[W_DIT(l, DIT_INP_B)]; da.mol_ptr = g->mol_ptr; da.B = B;
         da.Wqkv = nullptr; da.bqkv = nullptr; da.qkv = nullptr; da.mod_next = nullptr;
       }
-      PB("dit%d.chain", l);
       if (l == 2) {   // the last layer carries the atom and coordinate heads (model1.py:741-742)
         da.W0a = w[W_HEAD(0, HEAD_W0)]; da.b0a = w[W_HEAD(0, HEAD_B0)]; da.ga = w[W_HEAD(0, HEAD_G)]; da.bea = w[W_HEAD(0, HEAD_BE)];
         da.W3a = w[W_HEAD(0, HEAD_W3)]; da.b3a = w[W_HEAD(0, HEAD_B3)];
@@ -654,21 +647,8 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         da.W3p = w[W_HEAD(1, HEAD_W3)]; da.b3p = w[W_HEAD(1, HEAD_B3)];
         da.pos_upd = F(L.pos_upd); da.atom_pred = atom_pred; da.pos_pred = pos_pred;
       }
-      if (mol_wave) {
-        if (mstride == 0) {
-          if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_NONE, true>), grid, dim3(256), 0, s, da);
-          else hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_HEADS, true>), grid, dim3(256), 0, s, da);
-        } else {
-          if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<false, DIT_TAIL_NONE, true>), grid, dim3(256), 0, s, da);
-          else hipLaunchKernelGGL((dit_chain_kernel<false, DIT_TAIL_HEADS, true>), grid, dim3(256), 0, s, da);
-        }
-      } else if (mstride == 0) {
-        if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_QKV>), grid, dim3(256), 0, s, da);
-        else hipLaunchKernelGGL((dit_chain_kernel<true, DIT_TAIL_HEADS>), grid, dim3(256), 0, s, da);
-      } else {
-        if (l < 2) hipLaunchKernelGGL((dit_chain_kernel<false, DIT_TAIL_QKV>), grid, dim3(256), 0, s, da);
-        else hipLaunchKernelGGL((dit_chain_kernel<false, DIT_TAIL_HEADS>), grid, dim3(256), 0, s, da);
-      }
+      PB("dit%d.chain", l);
+      launch_dit_chain(da, l == 2 ? DIT_TAIL_HEADS : mol_wave ? DIT_TAIL_NONE : DIT_TAIL_QKV, mol_wave, s);
       PE();
       x_in = F(L.x2[l]);
       continue;
@@ -685,26 +665,6 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     if (!make_drop_site(drop, l, LIGDIFF_DROP_FFN_HIDDEN, &dh) || !make_drop_site(drop, l, LIGDIFF_DROP_FFN_OUT, &dout))
       return LIGDIFF_ERR_ARG;
     if ((dh.thr != 0u || dout.thr != 0u) && !use_cs()) return LIGDIFF_ERR_ARG;
-    // inference on the fp32 pipe: the whole feed-forward block as one launch (the [N,1024] hidden
-    // activations stay in registers); the next layer's pre-norm is fused as in the two-launch form
-    const bool chain = w_aligned && use_chain(N) && !L.save && dh.thr == 0u && dout.thr == 0u && g_split == nullptr && N > 0;
-    if (chain) {
-      FfnChainArgs fa;
-      memset(&fa, 0, sizeof fa);
-      fa.M = N; fa.XN = F(L.xn2[l]); fa.W1 = w[W_DIT(l, DIT_FF0_W)]; fa.b1 = w[W_DIT(l, DIT_FF0_B)];
-      fa.W2 = w[W_DIT(l, DIT_FF3_W)]; fa.b2 = w[W_DIT(l, DIT_FF3_B)]; fa.resid = F(L.x1[l]);
-      fa.mod = F(L.mod[l]); fa.mod_stride = mstride; fa.gate_off = 1280;
-      fa.mod2 = F(L.mod[l < 2 ? l + 1 : l]); fa.shift_off = 0; fa.scale_off = 256;
-      fa.atom_mol = g->atom_mol; fa.X = F(L.x2[l]); fa.XNout = l < 2 ? F(L.xn1[l + 1]) : F(L.x2[l]);
-      PB("dit%d.ffn", l);
-      if (l < 2)
-        hipLaunchKernelGGL((ffn_chain_kernel<true>), dim3(ceil_div(N, 128)), dim3(256), 0, s, fa);
-      else
-        hipLaunchKernelGGL((ffn_chain_kernel<false>), dim3(ceil_div(N, 128)), dim3(256), 0, s, fa);
-      PE();
-      x_in = F(L.x2[l]);
-      continue;
-    }
     PB("dit%d.ffn_up", l);
     if (dh.thr != 0u) {   // ffh = Dropout(GELU(xn2 W0^T + b)), model1.py:268-270
       GemmCore gc = core_blocks(N, 256, 256, w[W_DIT(l, DIT_FF0_W)], 256, 4, 256);

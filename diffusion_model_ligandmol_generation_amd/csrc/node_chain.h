@@ -14,31 +14,19 @@
 // fragments, and a spilled slab is reloaded in front of every MFMA group that uses it.
 #pragma once
 #include "chain.h"
+#include "chain_args.h"
 
-struct NodeChainArgs {
-  int M;
-  const float* h;       // [M,256]
-  const float* agg;     // [M,256]
-  float* hout;          // [M,256] (may be h)
-  const float* Wn1; const float* b1; const float* Wn2; const float* b2; const float* gamma; const float* beta;
-  // tail
-  const float* Wt; const float* bt;   // TAIL_PROJ: next layer's edge_network.0 weight [256,544] / bias; TAIL_QKV: in_proj [768,256] / bias
-  float* tout;                        // TAIL_PROJ: P [M,512]; TAIL_QKV: qkv [M,768]
-  const float* mod; int mod_stride; const int32_t* atom_mol;   // TAIL_QKV: first attention layer's adaLN rows (shift_msa | scale_msa | ...)
-  unsigned long long* stamps;   // diagnostic builds (DBG): [grid][8] shader-clock stamps of wave 0
-};
 
-enum { NODE_TAIL_NONE = 0, NODE_TAIL_PROJ = 1, NODE_TAIL_QKV = 2 };
 
 #define NC_VEC_B1 0
 #define NC_VEC_B2 256
 #define NC_VEC_G 512
 #define NC_VEC_BE 768
 #define NC_VEC_BT 1024     // tail bias: 512 (first half zero) or 768
-#define NC_VEC_MOD 1792    // 512: shift_msa | scale_msa (shared-timestep form)
+#define NC_VEC_MOD 1792    // 512: shift_msa | scale_msa
 #define NC_VEC_FL 2304
 
-template <int TAIL, bool SHARED, bool DBG = false>
+template <int TAIL, bool DBG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void node_chain_kernel(NodeChainArgs p) {
   __shared__ __attribute__((aligned(1024))) float smem[3 * CH_TILE_FL + NC_VEC_FL];
@@ -85,7 +73,7 @@ void node_chain_kernel(NodeChainArgs p) {
       else if (idx < 256) src = p.beta + (idx - 192) * 4;
       else if (TAIL == NODE_TAIL_PROJ && idx >= 320 && idx < 384) src = p.bt != nullptr ? p.bt + (idx - 320) * 4 : nullptr;
       else if (TAIL == NODE_TAIL_QKV && idx < 448) src = p.bt + (idx - 256) * 4;
-      else if (TAIL == NODE_TAIL_QKV && SHARED && idx >= 448 && idx < 576) src = p.mod + (idx - 448) * 4;
+      else if (TAIL == NODE_TAIL_QKV && idx >= 448 && idx < 576) src = p.mod + (idx - 448) * 4;
       v[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -210,7 +198,6 @@ void node_chain_kernel(NodeChainArgs p) {
   // ---- tail: NQ output tiles over the new slab, three per trip
   f32x16 (&xs)[8] = TAIL == NODE_TAIL_QKV ? as : hs;   // the tail's B slab
   if (TAIL == NODE_TAIL_QKV) {   // pre-norm of the first attention layer: LN(h'; eps 1e-6) (1 + scale) + shift
-    const float* mrow = SHARED ? nullptr : p.mod + (size_t)p.atom_mol[rr] * p.mod_stride + 4 * h;
     float s = 0.f;
 #pragma unroll
     for (int o = 0; o < 8; ++o)
@@ -227,8 +214,8 @@ void node_chain_kernel(NodeChainArgs p) {
     const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-6f);
 #pragma unroll
     for (int m = 0; m < 32; ++m) {
-      const f32x4 sh = SHARED ? vec4(NC_VEC_MOD, m) : *reinterpret_cast<const f32x4*>(mrow + 8 * m);
-      const f32x4 sc = SHARED ? vec4(NC_VEC_MOD + 256, m) : *reinterpret_cast<const f32x4*>(mrow + 256 + 8 * m);
+      const f32x4 sh = vec4(NC_VEC_MOD, m);
+      const f32x4 sc = vec4(NC_VEC_MOD + 256, m);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         as[m >> 2][4 * (m & 3) + k] = ((hs[m >> 2][4 * (m & 3) + k] - mean) * rstd) * (1.0f + sc[k]) + sh[k];

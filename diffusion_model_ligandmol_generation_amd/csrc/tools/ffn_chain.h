@@ -1,3 +1,4 @@
+// (First of the chain kernels, superseded in the library by dit_chain.h; kept as the reference launch of chain_bench.)
 // Fused feed-forward block of a DiT layer (inference form), model1.py:266-273 / :298-300:
 //   u  = GELU(xn W1^T + b1)                  [M,1024]   (never leaves the chip)
 //   x  = resid + gate[mol] * (u W2^T + b2)   [M,256]
@@ -28,7 +29,7 @@
 // In the transposed layout a LayerNorm row is a lane (plus its partner lane ^ 32), so the row
 // statistics need one cross-half exchange instead of a half-wave reduction per row.
 #pragma once
-#include "chain.h"
+#include "../chain.h"
 
 // GELU (erf form) with the constants of erf_fast2 folded: with t = |x| / sqrt 2 and
 // p = 1 + a1 t + ... + a6 t^6, erf(t) = 1 - p^-16, so

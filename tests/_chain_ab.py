@@ -25,8 +25,8 @@ def main(out_path):
 
     # (sizes, fully connected, one timestep for all molecules, properties)
     cases = [([29] * 40, False, True, False),              # benchmark shape, 1160 atoms (not a multiple of 128)
-             ([2, 5, 31, 33, 64, 7, 128, 19], False, False, True),
-             ([17, 40, 9], True, False, False),
+             ([2, 5, 31, 33, 64, 7, 128, 19], False, True, True),   # ragged rows, attention as its own launch
+             ([17, 40, 9], True, False, False),                     # per-molecule timesteps: fused E(3) kernels, separate attention layers
              ([3], False, True, True)]
     for ci, (sizes, fc, shared_t, props) in enumerate(cases):
         g = torch.Generator().manual_seed(100 + ci)
