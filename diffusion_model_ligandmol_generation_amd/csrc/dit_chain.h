@@ -117,10 +117,11 @@ void dit_chain_kernel(DitChainArgs p) {
 #pragma unroll
   for (int n = 0; n < 8; ++n) { fetch(0, n); fetch(1, n); }
 
-  // small vectors -> LDS (all loads first, then the writes)
+  // small vectors -> LDS: the loads go out here, the LDS writes follow the loads of the slab rows (stage_write below),
+  // so that the prologue waits for memory once
+  constexpr int NV = 1088;   // float4 slots
+  f32x4 sv[5], hv[3];
   {
-    constexpr int NV = 1088;   // float4 slots
-    f32x4 v[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int idx = tid + 256 * i;
@@ -131,17 +132,11 @@ void dit_chain_kernel(DitChainArgs p) {
       else if (idx < 640) src = p.b2 + (idx - 576) * 4;
       else if (idx < 896) src = p.b1 + (idx - 640) * 4;
       else if (idx < 1088) src = TAIL_QKV ? p.bqkv + (idx - 896) * 4 : MOLWAVE ? p.bqkv_self + (idx - 896) * 4 : nullptr;
-      v[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < NV) *reinterpret_cast<f32x4*>(vec + idx * 4) = v[i];
+      sv[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
 
   if (TAIL == DIT_TAIL_HEADS) {   // the heads' vectors (float4 slots 1088 ..): 128 x 6 hidden-layer vectors, 32 b3a, 192 W3p
-    f32x4 v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int idx = tid + 256 * i;
@@ -153,18 +148,27 @@ void dit_chain_kernel(DitChainArgs p) {
       else if (idx < 320) src = p.bea + (idx - 256) * 4;
       else if (idx < 384) src = p.bep + (idx - 320) * 4;
       else if (idx >= 416 && idx < 608) src = p.W3p + (idx - 416) * 4;
-      v[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+      hv[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
       if (idx >= 384 && idx < 416) {   // 119 floats: not a multiple of four
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[i][k] = (idx - 384) * 4 + k < 119 ? p.b3a[(idx - 384) * 4 + k] : 0.f;
+        for (int k = 0; k < 4; ++k) hv[i][k] = (idx - 384) * 4 + k < 119 ? p.b3a[(idx - 384) * 4 + k] : 0.f;
       }
     }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < 608) *reinterpret_cast<f32x4*>(vec + DC_VEC_HB0 + idx * 4) = v[i];
-    }
   }
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < NV) *reinterpret_cast<f32x4*>(vec + idx * 4) = sv[i];
+    }
+    if (TAIL == DIT_TAIL_HEADS) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < 608) *reinterpret_cast<f32x4*>(vec + DC_VEC_HB0 + idx * 4) = hv[i];
+      }
+    }
+  };
   // adaLN vector `off` (0 shift_msa .. 1280 gate_mlp), features 8m + 4h .. + 3, for this lane's molecule
   auto modv = [&](int off, int m) -> f32x4 { return *reinterpret_cast<const f32x4*>(vec + DC_VEC_MOD + off + 8 * m + 4 * h); };
   auto modv_next = [&](int off, int m) -> f32x4 { return *reinterpret_cast<const f32x4*>(vec + DC_VEC_MODN + off + 8 * m + 4 * h); };
@@ -270,12 +274,14 @@ void dit_chain_kernel(DitChainArgs p) {
   };
   if constexpr (!MOLWAVE) {
     load_rows(xs, p.att);
+    stage_write();
     open_step();   // ring tiles 0, 1 and the small vectors are in LDS
   } else {
     // ---- attention front: pre-norm of the wave's molecule, then per head q / k / v tiles (ring steps 3 hd ..),
     // S^T = K Q^T, softmax over the molecule's keys, O^T = V^T P^T
     f32x16 xn[8];
     load_rows(x1, p.x);
+    stage_write();
     open_step();
     ln_mod(x1, xn, [&](int m) { return modv(256, m); }, [&](int m) { return modv(0, m); });
     auto front_step = [&](auto S, f32x16& acc, auto SW) {   // ring step S over the pre-norm slab

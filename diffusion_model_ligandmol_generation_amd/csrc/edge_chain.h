@@ -35,26 +35,28 @@ void edge_chain_kernel(EdgeChainArgs p) {
   for (int n = 0; n < 8; ++n) cl.dma_tall(p.W2, 256, 0, ring, n);
 #pragma unroll
   for (int n = 0; n < 8; ++n) cl.dma_tall(p.W2, 256, 32, ring + CH_TILE_FL, n);
-  {
-    const float* sv = tid < 64 ? p.b2 + tid * 4 : tid < 128 ? p.gamma + (tid - 64) * 4
-                    : tid < 192 ? p.beta + (tid - 128) * 4 : tid < 224 ? p.bc1 + (tid - 192) * 4 : p.wc2 + (tid - 224) * 4;
-    *reinterpret_cast<f32x4*>(vec + tid * 4) = *reinterpret_cast<const f32x4*>(sv);
-  }
+  // prologue loads: the edge's end points first (the P gathers depend on them), everything else behind them, the LDS
+  // write of the small vectors last, so that the wave waits for memory twice (indices, then the rest) and not four times
   const int e_raw = blockIdx.x * 128 + cl.wave * 32 + fi;
   const int e = e_raw < p.E ? e_raw : p.E - 1;
+  const int i_src = p.src[e], i_dst = p.dst[e];
+  const float* svp = tid < 64 ? p.b2 + tid * 4 : tid < 128 ? p.gamma + (tid - 64) * 4
+                   : tid < 192 ? p.beta + (tid - 128) * 4 : tid < 224 ? p.bc1 + (tid - 192) * 4 : p.wc2 + (tid - 224) * 4;
+  const f32x4 sv = *reinterpret_cast<const f32x4*>(svp);
   f32x4 rb[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) rb[m] = *reinterpret_cast<const f32x4*>(p.rbf + (size_t)e * 32 + 8 * m + 4 * h);
   const f32x4 relv = *reinterpret_cast<const f32x4*>(p.rel + (size_t)e * 4);
   const float bc2 = p.bc2[0];
-  const float* pa = p.P + (size_t)p.src[e] * 512 + 4 * h;
-  const float* pb = p.P + (size_t)p.dst[e] * 512 + 256 + 4 * h;
+  const float* pa = p.P + (size_t)i_src * 512 + 4 * h;
+  const float* pb = p.P + (size_t)i_dst * 512 + 256 + 4 * h;
   f32x4 ga[4], gb[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     ga[g] = *reinterpret_cast<const f32x4*>(pa + 8 * g);
     gb[g] = *reinterpret_cast<const f32x4*>(pb + 8 * g);
   }
+  *reinterpret_cast<f32x4*>(vec + tid * 4) = sv;
   __syncthreads();
   stamp(1);
   f32x16 msg[8];

@@ -59,29 +59,30 @@ void node_chain_kernel(NodeChainArgs p) {
 #pragma unroll
   for (int n = 0; n < 8; ++n) { fetch(0, n); fetch(1, n); }
 
-  // small vectors -> LDS (all loads first, then the writes)
-  {
-    constexpr int NV = NC_VEC_FL / 4;   // float4 slots
-    f32x4 v[3];
+  // small vectors -> LDS: the loads go out here, the LDS writes follow the loads of the slab rows (stage_write below),
+  // so that the prologue waits for memory once
+  constexpr int NV = NC_VEC_FL / 4;   // float4 slots
+  f32x4 sv[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int idx = tid + 256 * i;
-      const float* src = nullptr;
-      if (idx < 64) src = p.b1 + idx * 4;
-      else if (idx < 128) src = p.b2 + (idx - 64) * 4;
-      else if (idx < 192) src = p.gamma + (idx - 128) * 4;
-      else if (idx < 256) src = p.beta + (idx - 192) * 4;
-      else if (TAIL == NODE_TAIL_PROJ && idx >= 320 && idx < 384) src = p.bt != nullptr ? p.bt + (idx - 320) * 4 : nullptr;
-      else if (TAIL == NODE_TAIL_QKV && idx < 448) src = p.bt + (idx - 256) * 4;
-      else if (TAIL == NODE_TAIL_QKV && idx >= 448 && idx < 576) src = p.mod + (idx - 448) * 4;
-      v[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < NV) *reinterpret_cast<f32x4*>(vec + idx * 4) = v[i];
-    }
+  for (int i = 0; i < 3; ++i) {
+    const int idx = tid + 256 * i;
+    const float* src = nullptr;
+    if (idx < 64) src = p.b1 + idx * 4;
+    else if (idx < 128) src = p.b2 + (idx - 64) * 4;
+    else if (idx < 192) src = p.gamma + (idx - 128) * 4;
+    else if (idx < 256) src = p.beta + (idx - 192) * 4;
+    else if (TAIL == NODE_TAIL_PROJ && idx >= 320 && idx < 384) src = p.bt != nullptr ? p.bt + (idx - 320) * 4 : nullptr;
+    else if (TAIL == NODE_TAIL_QKV && idx < 448) src = p.bt + (idx - 256) * 4;
+    else if (TAIL == NODE_TAIL_QKV && idx >= 448 && idx < 576) src = p.mod + (idx - 448) * 4;
+    sv[i] = src != nullptr ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < NV) *reinterpret_cast<f32x4*>(vec + idx * 4) = sv[i];
+    }
+  };
   auto vec4 = [&](int off, int m) -> f32x4 { return *reinterpret_cast<const f32x4*>(vec + off + 8 * m + 4 * h); };
 
   auto open_step = [&]() {
@@ -133,6 +134,7 @@ void node_chain_kernel(NodeChainArgs p) {
     });
   };
   load_slab(as, p.agg);
+  stage_write();
   open_step();
   stamp(1);
   // ---- first linear, agg half: pre[t] = b1 + Wn1[32t.., 256..511] . agg
