@@ -534,7 +534,8 @@ def run_rank(args):
                        "molecules_per_gpu": MOLS_PER_GPU, "atoms_per_molecule": ATOMS,
                        "edges_per_molecule": 62, "ddpm_steps": T_STEPS, "guidance": "none",
                        "gemm_mode": mode_name(split_mode),
-                       "parallelism": f"molecule-sharded x{world}, no collectives"},
+                       "parallelism": f"molecule-sharded x{world}, no collectives",
+                       "streams_per_gpu": "2 (the batch runs as two concurrent halves of 512 molecules; same bits as one call)"},
             "attempted_molecules": world * MOLS_PER_GPU * args.steps,
             "accepted_rank0": accepted, "finite": finite,
             "roofline": roofline, "roofline_aggregation": roofline_agg,

@@ -129,6 +129,12 @@ bool split_gemm_enabled() {
   return m != 0;
 }
 bool fwd_column_split_gemms() { return use_cs(); }
+static std::atomic<int> g_concurrent_calls{1};
+int chain_concurrent_calls() { return g_concurrent_calls.load(std::memory_order_relaxed); }
+extern "C" int ligdiff_set_concurrent_calls(int k) {
+  if (k < 1 || k > 16) return -1;
+  return g_concurrent_calls.exchange(k, std::memory_order_relaxed);
+}
 extern "C" int ligdiff_set_split_gemm(int enabled) {
   const int prev = split_gemm_enabled() ? 1 : 0;
   g_split_mode.store(enabled ? 1 : 0, std::memory_order_relaxed);

@@ -53,10 +53,14 @@ static inline int device_cus() {   // compute units of the current device
   if (cus[dev] == 0 && hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus[dev] = 256;
   return cus[dev] > 0 ? cus[dev] : 256;
 }
+// Callers that run k independent sub-batches concurrently on k streams of one GPU say so with
+// ligdiff_set_concurrent_calls(k): a launch then shares the chip with k - 1 like it, and the fill is judged on k times
+// its own workgroups.
+int chain_concurrent_calls();
 static inline bool use_chain(int64_t rows) {
   const int mode = chain_mode();
   if (mode != 1) return mode == 2;
-  const int64_t n = (rows + 127) / 128, cu = device_cus();
+  const int64_t n = (rows + 127) / 128 * chain_concurrent_calls(), cu = device_cus();
   const int64_t rounds = (n + cu - 1) / cu;
   return n > 0 && 4 * n >= 3 * rounds * cu;   // last round included, at least three quarters of the slots are used
 }

@@ -126,6 +126,18 @@ class ScoreNetworkEngine:
         Process-wide (include/ligdiff.h: ligdiff_set_split_gemm)."""
         return bool(self.lib.ligdiff_set_split_gemm(1 if enabled else 0))
 
+    def ddpm_workspace_bytes(self, graph, guided, n_steps):
+        return int(self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols,
+                                                                1 if guided else 0, int(n_steps)))
+
+    def set_concurrent_calls(self, k):
+        """Hint for k concurrent library calls on one GPU (include/ligdiff.h: ligdiff_set_concurrent_calls);
+        returns the previous value."""
+        prev = int(self.lib.ligdiff_set_concurrent_calls(int(k)))
+        if prev < 0:
+            raise ValueError("concurrent calls must be 1..16")
+        return prev
+
     def workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -313,14 +325,30 @@ class ScoreNetworkEngine:
                                             int(step), int(atom_offset), _stream()), "ligdiff_pos_step")
 
     def ddpm_sample(self, model, graph, x, pos, properties=None, guidance_scale=1.0, temperature=1.0,
-                    n_steps=None, seed=0, atom_offset=0, use_graph=True):
-        """Whole reverse loop in the library (hipGraph replay); x / pos updated in place."""
+                    n_steps=None, seed=0, atom_offset=0, use_graph=True, workspace=None, stream=None):
+        """Whole reverse loop in the library (hipGraph replay); x / pos updated in place.
+        workspace / stream: a caller that runs several of these calls concurrently (one host thread each)
+        gives every call its own workspace tensor and its own non-default stream; the call then returns
+        with the loop finished on that stream and leaves the current stream alone."""
         n_steps = model.timesteps if n_steps is None else n_steps
         self._check_sizes(graph)
         guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
         nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
                                                               int(n_steps))
-        ws = self.workspace(nbytes)
+        if workspace is not None and workspace.numel() < nbytes:
+            raise ValueError("workspace too small")
+        ws = self.workspace(nbytes) if workspace is None else workspace
+        if stream is not None:
+            if properties is not None:
+                properties = properties.contiguous().float()
+            with torch.cuda.device(self.device), torch.cuda.stream(stream):
+                rc = self.lib.ligdiff_ddpm_sample(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
+                                                  float(guidance_scale), float(temperature), _ptr(model.betas),
+                                                  _ptr(model.alphas), _ptr(model.alphas_cumprod), int(n_steps),
+                                                  int(seed), int(atom_offset), 1 if use_graph else 0, _ptr(ws),
+                                                  ws.numel(), C.c_void_p(stream.cuda_stream))
+            check(rc, "ligdiff_ddpm_sample")
+            return
         if properties is not None:
             properties = properties.contiguous().float()
             if properties.shape != (graph.n_mols, 15):

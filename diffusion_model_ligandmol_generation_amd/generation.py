@@ -38,6 +38,11 @@ class ResearchValidatedGenerator:
         self.device = next(model.parameters()).device
         self.batch_atoms = 32768          # atoms per packed sampling batch
         self.batch_edges = 4 << 20        # directed edges per packed sampling batch (fully connected molecules)
+        # A DDPM batch of at least this many atoms runs as TWO concurrent halves (two host threads, two streams):
+        # molecules are independent and the Gaussian draws are keyed by the global atom index, so the result is
+        # bit for bit the one of the single call, and one half's memory-bound kernels and launch ramps fall into
+        # the other's matrix time (2.40 -> 2.34 ms per reverse step at 1024 x 29 atoms).  None switches it off.
+        self.concurrent_atoms = 25600
         # Philox seed of the next call.  None: every call draws a fresh 62-bit seed from torch's global
         # CPU generator, so consecutive calls differ (as the reference's torch.randn draws do,
         # generation.py:291, :405, :469) and torch.manual_seed makes a run repeatable.  An int: used
@@ -116,6 +121,45 @@ class ResearchValidatedGenerator:
                 i = j
         return results, flags
 
+    def _ddpm_two_halves(self, sizes, connectivity, x, pos, props, guidance_scale, temperature, T, seed, atom_offset):
+        """The reverse loop of one batch as two concurrent library calls on contiguous halves of the molecules
+        (balanced by atoms, or by atom pairs for fully connected graphs); x / pos updated in place."""
+        import threading
+        from .parallel import shard_ranges
+        model, eng, dev = self.model, self.model.engine(), self.device
+        guided = props is not None and guidance_scale > 1.0
+        jobs = []
+        cur = torch.cuda.current_stream(dev)
+        for lo, hi in shard_ranges(sizes, 2, "pairs" if connectivity == "full" else "atoms"):
+            part = sizes[lo:hi]
+            a0, a1 = sum(int(n) for n in sizes[:lo]), sum(int(n) for n in sizes[:hi])
+            g = full_graph(part, dev)[0] if connectivity == "full" else template_graph(part, dev)[0]
+            ws = torch.empty(eng.ddpm_workspace_bytes(g, guided, T), dtype=torch.uint8, device=dev)
+            st = torch.cuda.Stream(device=dev)
+            st.wait_stream(cur)
+            jobs.append((g, x[a0:a1], pos[a0:a1], None if props is None else props[lo:hi], atom_offset + a0, ws, st))
+        errors = []
+
+        def run(job):
+            g, xs, ps, pr, off, ws, st = job
+            try:
+                eng.ddpm_sample(model, g, xs, ps, pr, guidance_scale, temperature, T, seed, off, True, workspace=ws, stream=st)
+            except Exception as e:   # noqa: BLE001  (re-raised on the calling thread)
+                errors.append(e)
+        prev = eng.set_concurrent_calls(len(jobs))
+        try:
+            threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            eng.set_concurrent_calls(prev)
+        for job in jobs:
+            cur.wait_stream(job[6])
+        if errors:
+            raise errors[0]
+
     def sample_batch(self, sizes, target_properties=None, guidance_scale=2.0, temperature=1.0, use_ddim=False,
                      num_steps=100, seed=None, atom_offset=0, noise=None, use_graph=True, trace=None,
                      connectivity="template"):
@@ -162,7 +206,11 @@ class ResearchValidatedGenerator:
             pos = (noise("pos0", T, (N, 3)) * temperature).contiguous()
         rejected = torch.zeros(B, dtype=torch.int32, device=dev)
         if not use_ddim and noise is None and trace is None:
-            eng.ddpm_sample(model, graph, x, pos, props, guidance_scale, temperature, T, seed, atom_offset, use_graph)
+            if (use_graph and self.concurrent_atoms is not None and N >= self.concurrent_atoms and B >= 8
+                    and connectivity in ("template", "full")):
+                self._ddpm_two_halves(sizes, connectivity, x, pos, props, guidance_scale, temperature, T, seed, atom_offset)
+            else:
+                eng.ddpm_sample(model, graph, x, pos, props, guidance_scale, temperature, T, seed, atom_offset, use_graph)
             return x, pos, graph, rejected
         t_index = torch.zeros(1, dtype=torch.int32, device=dev)
         if use_ddim:

@@ -11,6 +11,7 @@
  *  - the GEMM mode (ligdiff_set_split_gemm, or LIGDIFF_GEMM_SPLIT in the environment): it changes what
  *    the *_workspace_bytes functions return, so size workspaces after choosing it and do not switch
  *    while another thread is inside a call;
+ *  - the concurrency hint (ligdiff_set_concurrent_calls);
  *  - LIGDIFF_CFG_TWO_PASS (environment, read at every sampling call and workspace query);
  *  - A/B switches read once from the environment (LIGDIFF_GEMM_V1, LIGDIFF_GEMM_NOCS, LIGDIFF_CHAIN / LIGDIFF_NO_CHAIN, LIGDIFF_ATT_LDS,
  *    LIGDIFF_ATT_BWD_V1, LIGDIFF_DW_BLOCKS);
@@ -291,6 +292,13 @@ int ligdiff_loss_finish(const ligdiff_loss_args* args, const float* sums8, float
  * and do not switch while a call is running.  No counterpart in the reference (torch.nn.Linear in
  * fp32 throughout, model1.py:60-114, :255-302). */
 int ligdiff_set_split_gemm(int enabled);
+
+/* Tells the library that the caller is about to run k (1..16) independent calls concurrently on k streams of one
+ * GPU (e.g. the halves of a sampling batch from two host threads: molecules are independent, generation.py:38-160
+ * samples them one at a time).  Only the choice between the fused chain kernels and the separate launches looks at it
+ * (a launch is judged on k times its own workgroups); results do not depend on it beyond that choice.  Process-wide
+ * like the GEMM mode; returns the previous value, -1 for k out of range.  No counterpart in the reference. */
+int ligdiff_set_concurrent_calls(int k);
 
 /* Byte offsets, inside the workspace of a completed ligdiff_forward call with the same sizes and
  * flags, of the final hidden state h [n_atoms,256] (model1.py:738) and of pos + pos_updates

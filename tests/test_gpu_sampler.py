@@ -133,6 +133,23 @@ def test_graph_replay_equals_host_loop_and_sharding_is_bitwise_invariant():
     assert torch.isfinite(xa).all() and torch.isfinite(pa).all()
 
 
+@pytest.mark.parametrize("connectivity", ["template", "full"])
+def test_two_concurrent_halves_equal_the_single_call_bitwise(connectivity):
+    """Large DDPM batches run as two concurrent library calls on two streams (generation.py here:
+    _ddpm_two_halves); forced on a small batch it must reproduce the single call bit for bit, guided or not."""
+    gen = _gen(T=20)
+    sizes = [9, 17, 29, 5, 30, 12, 8, 21, 16, 25] if connectivity == "template" else [9, 12, 7, 5, 10, 6, 8, 11]
+    props = torch.linspace(-1.0, 1.0, 15).reshape(1, 15)
+    for target, scale in ((None, 1.0), (props, 2.0)):
+        gen.concurrent_atoms = None
+        xa, pa, _, _ = gen.sample_batch(sizes, target, scale, 1.0, seed=5, connectivity=connectivity)
+        gen.concurrent_atoms = 1
+        xb, pb, _, _ = gen.sample_batch(sizes, target, scale, 1.0, seed=5, connectivity=connectivity)
+        assert torch.equal(xa, xb) and torch.equal(pa, pb)
+        assert torch.isfinite(xa).all() and torch.isfinite(pa).all()
+    assert gen.model.engine().set_concurrent_calls(1) == 1    # the hint is restored after the call
+
+
 def test_philox_normal_statistics_and_determinism():
     gen = _gen(T=20)
     eng = gen.model.engine()
