@@ -1,6 +1,8 @@
 """Reverse-step time against batch size (29-atom template ligands, unguided DDPM, graph replay) in both
 GEMM modes: how far the benchmark's 1024 molecules per GPU are from filling the part.
-Usage: python tools/batch_sweep.py [steps]"""
+Usage: python tools/batch_sweep.py [steps [molecules ...]]
+SWEEP_CONCURRENT_ATOMS in the environment overrides the generator's threshold for running a batch as two
+concurrent halves ("none": never)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,8 +14,12 @@ torch.manual_seed(0)
 model = ResearchAccurateDiffusionModel(timesteps=steps).cuda().eval()
 gen = ResearchValidatedGenerator(model)
 eng = model.engine()
+if "SWEEP_CONCURRENT_ATOMS" in os.environ:
+    v = os.environ["SWEEP_CONCURRENT_ATOMS"]
+    gen.concurrent_atoms = None if v == "none" else int(v)
 print(f"{'molecules':>9} {'atoms':>7} | {'fp32 ms/step':>12} {'mol/s @1000':>11} | {'split ms/step':>13} {'mol/s @1000':>11}")
-for B in (128, 256, 512, 1024, 1130, 2048, 2260, 4096, 8192):
+batches = [int(a) for a in sys.argv[2:]] or [128, 256, 512, 1024, 1130, 2048, 2260, 4096, 8192]
+for B in batches:
     sizes = [29] * B
     row = []
     for split in (False, True):
