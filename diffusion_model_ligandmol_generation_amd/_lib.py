@@ -93,6 +93,7 @@ SIGNATURES = {
     "ligdiff_ddim_step": (C.c_int, [C.POINTER(StepArgs), C.c_int32, C.c_int32, C.c_void_p]),
     "ligdiff_set_split_gemm": (C.c_int, [C.c_int]),
     "ligdiff_set_concurrent_calls": (C.c_int, [C.c_int]),
+    "ligdiff_set_chain_mode": (C.c_int, [C.c_int]),
     "ligdiff_forward_state_offsets": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int, C.POINTER(C.c_size_t),
                                                 C.POINTER(C.c_size_t)]),
     "ligdiff_consistency_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),

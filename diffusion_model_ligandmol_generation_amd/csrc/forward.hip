@@ -129,6 +129,12 @@ bool split_gemm_enabled() {
   return m != 0;
 }
 bool fwd_column_split_gemms() { return use_cs(); }
+static std::atomic<int> g_chain_mode{-1};
+int chain_mode_override() { return g_chain_mode.load(std::memory_order_relaxed); }
+extern "C" int ligdiff_set_chain_mode(int mode) {
+  if (mode < -1 || mode > 2) return -2;
+  return g_chain_mode.exchange(mode, std::memory_order_relaxed);
+}
 static std::atomic<int> g_concurrent_calls{1};
 int chain_concurrent_calls() { return g_concurrent_calls.load(std::memory_order_relaxed); }
 extern "C" int ligdiff_set_concurrent_calls(int k) {

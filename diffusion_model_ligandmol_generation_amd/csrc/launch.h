@@ -33,6 +33,7 @@ static inline bool use_cs() {
 // batch) is faster on the separate launches, whose column blocks spread over the chip (29-atom ligands:
 // 512 molecules 1.89 against 2.11 ms per reverse step, 600 molecules 2.42 against 2.32; beyond one round
 // the chain kernels win at every size measured, 257 workgroups included).
+int chain_mode_override();          // ligdiff_set_chain_mode: -1 = as the environment says
 static inline int chain_mode() {   // 0 off, 1 by fill, 2 force
   static const int v = [] {
     if (getenv("LIGDIFF_GEMM_NOCS") != nullptr || getenv("LIGDIFF_GEMM_V1") != nullptr || getenv("LIGDIFF_NO_CHAIN") != nullptr) return 0;
@@ -41,7 +42,8 @@ static inline int chain_mode() {   // 0 off, 1 by fill, 2 force
     if (e[0] == '0') return 0;
     return (e[0] == 'f' || e[0] == 'F') ? 2 : 1;
   }();
-  return v;
+  const int o = chain_mode_override();
+  return o >= 0 ? o : v;
 }
 // Molecule-per-wave form of the attention-layer kernel (attention inside it) unless LIGDIFF_CHAIN_MOL=0 (A/B switch).
 static inline bool chain_mol_allowed() {

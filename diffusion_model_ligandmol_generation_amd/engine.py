@@ -138,6 +138,14 @@ class ScoreNetworkEngine:
             raise ValueError("concurrent calls must be 1..16")
         return prev
 
+    def set_chain_mode(self, mode):
+        """Fused chain kernels: 0 never, 1 by chip fill, 2 always, -1 as the environment says
+        (include/ligdiff.h: ligdiff_set_chain_mode); returns the previous setting."""
+        prev = int(self.lib.ligdiff_set_chain_mode(int(mode)))
+        if prev < -1:
+            raise ValueError("chain mode must be -1..2")
+        return prev
+
     def workspace(self, nbytes):
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)

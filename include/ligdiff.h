@@ -11,9 +11,10 @@
  *  - the GEMM mode (ligdiff_set_split_gemm, or LIGDIFF_GEMM_SPLIT in the environment): it changes what
  *    the *_workspace_bytes functions return, so size workspaces after choosing it and do not switch
  *    while another thread is inside a call;
- *  - the concurrency hint (ligdiff_set_concurrent_calls);
+ *  - the concurrency hint (ligdiff_set_concurrent_calls) and the chain-kernel choice (ligdiff_set_chain_mode);
  *  - LIGDIFF_CFG_TWO_PASS (environment, read at every sampling call and workspace query);
- *  - A/B switches read once from the environment (LIGDIFF_GEMM_V1, LIGDIFF_GEMM_NOCS, LIGDIFF_CHAIN / LIGDIFF_NO_CHAIN, LIGDIFF_ATT_LDS,
+ *  - A/B switches read once from the environment (LIGDIFF_GEMM_V1, LIGDIFF_GEMM_NOCS, LIGDIFF_CHAIN / LIGDIFF_NO_CHAIN, LIGDIFF_CHAIN_MOL,
+ *    LIGDIFF_ATT_LDS,
  *    LIGDIFF_ATT_BWD_V1, LIGDIFF_DW_BLOCKS);
  *  - the per-device scratch array of ligdiff_pack_csr_static.
  * HIP objects created and destroyed inside a call: ligdiff_ddpm_sample / ligdiff_ddim_sample with
@@ -299,6 +300,13 @@ int ligdiff_set_split_gemm(int enabled);
  * (a launch is judged on k times its own workgroups); results do not depend on it beyond that choice.  Process-wide
  * like the GEMM mode; returns the previous value, -1 for k out of range.  No counterpart in the reference. */
 int ligdiff_set_concurrent_calls(int k);
+
+/* Choice between the fused chain kernels and the separate launches on the inference path: 0 never, 1 by how well a
+ * launch fills the chip, 2 always, -1 (initial state) as LIGDIFF_CHAIN in the environment says.  Process-wide like the
+ * GEMM mode; returns the previous setting, -2 for a mode out of range.  Both forms compute the same layers
+ * (model1.py:60-114, :255-302, :340-410) and agree to rounding.  No counterpart in the reference: measurement and A/B
+ * runs use it (a label of ligdiff_forward_timed exists only in the form that launches it). */
+int ligdiff_set_chain_mode(int mode);
 
 /* Byte offsets, inside the workspace of a completed ligdiff_forward call with the same sizes and
  * flags, of the final hidden state h [n_atoms,256] (model1.py:738) and of pos + pos_updates

@@ -48,3 +48,31 @@ def test_chain_kernels_match_separate_launches(tmp_path):
             scale = max(1.0, float(np.abs(b).max()))
             tol = (2e-4 if k.startswith("s_") else 2e-5) * scale
             assert float(np.abs(a - b).max()) <= tol, (name, k, float(np.abs(a - b).max()), scale)
+
+
+def test_chain_mode_switch_in_process():
+    """ligdiff_set_chain_mode: the run-time override of LIGDIFF_CHAIN returns the previous setting, rejects
+    modes out of range, and the two forms it selects agree on one sampling call."""
+    import torch
+    from diffusion_model_ligandmol_generation_amd import ResearchAccurateDiffusionModel
+    from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
+    torch.manual_seed(0)
+    model = ResearchAccurateDiffusionModel().cuda().eval()
+    eng = model.engine()
+    gen = ResearchValidatedGenerator(model)
+    prev = eng.set_chain_mode(0)
+    try:
+        assert prev == -1
+        with pytest.raises(ValueError):
+            eng.set_chain_mode(3)
+        assert eng.set_chain_mode(0) == 0   # a rejected mode leaves the setting alone
+        x0, p0, _, _ = gen.sample_batch([29] * 12, None, 1.0, 1.0, num_steps=10, seed=3)
+        assert eng.set_chain_mode(2) == 0
+        x2, p2, _, _ = gen.sample_batch([29] * 12, None, 1.0, 1.0, num_steps=10, seed=3)
+    finally:
+        eng.set_chain_mode(prev)
+    assert torch.isfinite(x2).all() and torch.isfinite(p2).all()
+    assert not torch.equal(x0, x2)          # different kernels, different summation orders
+    for a, b in ((x0, x2), (p0, p2)):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 1e-4 * scale
