@@ -414,13 +414,19 @@ def run_rank(args):
             accept = eng.validity_gate(x, pos, graph.mol_ptr, graph.n_mols)
         return x, pos, int(accept.sum().item())
 
+    pass_ends = []    # host clock after each timed pass of the last timed_run (a pass ends with the gate's .item())
+
     def timed_run(warmup, steps):
         accepted = [0]
+        pass_ends.clear()
 
         def fn(i):
+            if i == 0:
+                pass_ends.append(time.time())
             x, pos, acc = one_pass(i)
             if i < 10_000:
                 accepted[0] += acc
+                pass_ends.append(time.time())
             return x, pos
         dt, (x, pos) = ctx.timed(fn, warmup, steps)
         return dt, accepted[0], x, pos
@@ -431,6 +437,7 @@ def run_rank(args):
     eng.set_split_gemm(split_mode)
     log(ctx, f"headline: {args.warmup} warm-up + {args.steps} timed passes of {MOLS_PER_GPU} molecules x {T_STEPS} steps ...")
     dt, accepted, x, pos = timed_run(args.warmup, args.steps)
+    pass_seconds = [round(b - a, 4) for a, b in zip(pass_ends, pass_ends[1:])]
     log(ctx, f"headline done: {dt:.2f} s; other GEMM mode ...")
     finite = bool(torch.isfinite(x).all() and torch.isfinite(pos).all())
     # (every rank runs it, so the barriers inside stay matched; a failure here must not lose the headline)
@@ -539,6 +546,7 @@ def run_rank(args):
                        "parallelism": f"molecule-sharded x{world}, no collectives",
                        "streams_per_gpu": ("1 (--one-call)" if args.one_call else
                                            "2 (the batch runs as two concurrent halves of 512 molecules; same bits as one call)")},
+            "pass_seconds_rank0": pass_seconds,
             "attempted_molecules": world * MOLS_PER_GPU * args.steps,
             "accepted_rank0": accepted, "finite": finite,
             "roofline": roofline, "roofline_aggregation": roofline_agg,
