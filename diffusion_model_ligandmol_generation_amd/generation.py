@@ -41,8 +41,9 @@ class ResearchValidatedGenerator:
         # A DDPM batch of at least this many atoms runs as TWO concurrent halves (two host threads, two streams):
         # molecules are independent and the Gaussian draws are keyed by the global atom index, so the result is
         # bit for bit the one of the single call, and one half's memory-bound kernels and launch ramps fall into
-        # the other's matrix time (2.40 -> 2.34 ms per reverse step at 1024 x 29 atoms).  None switches it off.
-        self.concurrent_atoms = 25600
+        # the other's matrix time (2.40 -> 2.34 ms per reverse step at 1024 x 29 atoms; 600 molecules 2.33 -> 2.20,
+        # neutral from 700 to 900, and a loss below 550, where a half no longer fills half of the chip).  None switches it off.
+        self.concurrent_atoms = 17000
         self._half_streams = []
         # Philox seed of the next call.  None: every call draws a fresh 62-bit seed from torch's global
         # CPU generator, so consecutive calls differ (as the reference's torch.randn draws do,
