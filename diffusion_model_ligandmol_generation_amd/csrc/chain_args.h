@@ -1,6 +1,6 @@
 // Argument blocks and host-side launchers of the fused chain kernels (edge_chain.h, node_chain.h, dit_chain.h).
-// The kernels are compiled in translation units of their own (chain_e3.hip, chain_dit_row.hip,
-// chain_dit_mol.hip): each instantiation is ten thousand instructions of straight-line code and takes minutes
+// The kernels are compiled in translation units of their own (chain_e3.hip, chain_dit_row*.hip,
+// chain_dit_mol*.hip): each instantiation is ten thousand instructions of straight-line code and takes minutes
 // to compile, so they build in parallel with the rest of the library.
 #pragma once
 #include <hip/hip_runtime.h>

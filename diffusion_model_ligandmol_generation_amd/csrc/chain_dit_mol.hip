@@ -1,8 +1,10 @@
-// Fused attention layer, molecule-per-wave form (attention inside the kernel): kernel instantiations and
-// the launcher of both forms.
+// Fused attention layer, molecule-per-wave form (attention inside the kernel): the instantiation without a tail
+// and the launcher of both forms.  The instantiations with the output heads sit in translation units of their own
+// (chain_dit_mol_heads.hip, chain_dit_row_heads.hip): each takes minutes to compile.
 #include "dit_chain.h"
 
 void launch_dit_chain_row(const DitChainArgs& a, int tail, hipStream_t s);
+void launch_dit_chain_mol_heads(const DitChainArgs& a, dim3 grid, hipStream_t s);
 
 void launch_dit_chain(const DitChainArgs& a, int tail, bool mol_wave, hipStream_t s) {
   if (a.M <= 0) return;
@@ -11,6 +13,6 @@ void launch_dit_chain(const DitChainArgs& a, int tail, bool mol_wave, hipStream_
     return;
   }
   const dim3 grid((a.B + 3) / 4);
-  if (tail == DIT_TAIL_HEADS) hipLaunchKernelGGL((dit_chain_kernel<DIT_TAIL_HEADS, true>), grid, dim3(256), 0, s, a);
+  if (tail == DIT_TAIL_HEADS) launch_dit_chain_mol_heads(a, grid, s);
   else hipLaunchKernelGGL((dit_chain_kernel<DIT_TAIL_NONE, true>), grid, dim3(256), 0, s, a);
 }
