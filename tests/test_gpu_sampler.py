@@ -148,6 +148,11 @@ def test_two_concurrent_halves_equal_the_single_call_bitwise(connectivity):
         assert torch.equal(xa, xb) and torch.equal(pa, pb)
         assert torch.isfinite(xa).all() and torch.isfinite(pa).all()
     assert gen.model.engine().set_concurrent_calls(1) == 1    # the hint is restored after the call
+    # every call reuses ONE pair of side streams (a fresh pair per call was seen to land on one hardware queue)
+    assert len(gen._half_streams) == 2
+    first = [s.cuda_stream for s in gen._half_streams]
+    gen.sample_batch(sizes, None, 1.0, 1.0, seed=6, connectivity=connectivity)
+    assert [s.cuda_stream for s in gen._half_streams] == first
 
 
 def test_philox_normal_statistics_and_determinism():
