@@ -50,17 +50,24 @@ __device__ __forceinline__ void wait_vm_count() {
 
 // NTW = accumulators per wave: 4 -> 256-column blocks (the common case), 2 -> 128-column blocks
 // (coordinate gate, atom head), whose stage is 128 + 128 rows and whose waves issue two DMAs per chunk.
-template <class AP, class EPI, int NTW = 4>
-__global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI epi) {
-  constexpr int A_FL = 128 * G2_ROWF;
-  constexpr int ST = (128 + 64 * NTW) * G2_ROWF;
+// SLABS = 32-row slabs per workgroup (2 * SLABS waves): 4 -> 128 rows, the form for launches that fill the chip.
+// A launch of few rows (M / 128 well below the number of CUs) puts its waves two to a SIMD on a fraction of
+// the CUs while the rest idle, and a wave's 32 x 128 x K tile is a fixed chain of K / 2 x 4 MFMAs of 64 cycles:
+// with SLABS = 2 or 1 the same waves spread over four or eight times as many CUs (the weight chunk is then
+// copied once per 64 or 32 rows instead of once per 128, from L2).  A row's products and sums are the same
+// instructions in the same order for every SLABS, so the result does not depend on it.
+template <class AP, class EPI, int NTW = 4, int SLABS = 4>
+__global__ __launch_bounds__(128 * SLABS, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI epi) {
+  constexpr int A_FL = 32 * SLABS * G2_ROWF;
+  constexpr int ST = (32 * SLABS + 64 * NTW) * G2_ROWF;
+  constexpr int WP = 2 * NTW / SLABS;   // 16-row W pieces per wave and chunk (4 * NTW pieces over 2 * SLABS waves)
   __shared__ __attribute__((aligned(1024))) float smem3[3 * ST + 4 * 256];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int slab = wave & 3, half = wave >> 2;
+  const int slab = wave % SLABS, half = wave / SLABS;
   const int by = blockIdx.y;
-  const int row_blk = blockIdx.x * 128;
+  const int row_blk = blockIdx.x * (32 * SLABS);
   const float* __restrict__ W = g.W[by];
 
   f32x16 acc[NTW];
@@ -69,15 +76,15 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 
-  // DMA roles (see gemm2.h): one A piece (16 rows) and NTW/2 W pieces per wave and chunk
+  // DMA roles (see gemm2.h): one A piece (16 rows) and WP W pieces per wave and chunk
   const int pr = lane >> 2, ps = lane & 3;
   const int lslot = ps ^ ((pr >> 2) & 3);
   int a_row = row_blk + wave * 16 + pr;
   a_row = a_row < g.M ? a_row : g.M - 1;
-  const float* w_src[NTW / 2];
+  const float* w_src[WP];
 #pragma unroll
-  for (int i = 0; i < NTW / 2; ++i) {
-    int n = (wave * (NTW / 2) + i) * 16 + pr;
+  for (int i = 0; i < WP; ++i) {
+    int n = (wave * WP + i) * 16 + pr;
     n = n < g.n_valid ? n : g.n_valid - 1;
     w_src[i] = W + (size_t)n * g.ldw + lslot * 4;
   }
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI 
     const int k0 = kc * G2_BK;
     lds_dma16(ap.ptr(a_row, k0 + lslot * 4), sA + wave * 256);
 #pragma unroll
-    for (int i = 0; i < NTW / 2; ++i) lds_dma16(w_src[i] + k0, sW + (wave * (NTW / 2) + i) * 256);
+    for (int i = 0; i < WP; ++i) lds_dma16(w_src[i] + k0, sW + (wave * WP + i) * 256);
   };
 
   const int nk = g.K / G2_BK;
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI 
   for (int kc = 0; kc < nk; ++kc) {
     // own DMAs of chunk kc done (the newest chunk may stay in flight), then join: every
     // wave's part of chunk kc is in LDS and nobody still reads the stage refilled below
-    if (kc + 1 < nk) wait_vm_count<1 + NTW / 2>();
+    if (kc + 1 < nk) wait_vm_count<1 + WP>();
     else wait_vm_count<0>();
     __builtin_amdgcn_s_barrier();
     if (kc + 2 < nk) issue(kc + 2, cur == 0 ? 2 : cur - 1);
@@ -130,6 +137,6 @@ __global__ __launch_bounds__(512, 2) void gemm_cs_kernel(GemmCore g, AP ap, EPI 
     }
     cur = cur == 2 ? 0 : cur + 1;
   }
-  HalfMailbox mb{smem3 + 3 * ST, wave, lane};
+  HalfMailbox mb{smem3 + 3 * ST, slab + 4 * half, lane};   // mailbox slots are numbered as in the 8-wave form
   epi.cs(acc, row_blk + slab * 32, by, half, lane, mb);
 }

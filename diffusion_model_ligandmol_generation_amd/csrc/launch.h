@@ -67,6 +67,15 @@ static inline bool use_chain(int64_t rows) {
   const int64_t n = (rows + 127) / 128 * chain_concurrent_calls(), cu = device_cus();
   return n > 0 && 2 * n >= cu;   // at least half of the chip's workgroup slots are used
 }
+// Column-split GEMM launches of few rows: a 128-row workgroup is eight waves, two to a SIMD, and a wave's tile is a
+// fixed chain of MFMAs, so a launch whose 128-row workgroups cover at most half of the CUs runs as 64-row
+// workgroups (four waves, one to a SIMD, on twice as many CUs) in about half the time.  Same bits either way
+// (LIGDIFF_GEMM_TILE64=0 switches the choice off for A/B runs).
+static inline bool half_tiles(int M, int nb) {
+  static const bool on = [] { const char* e = getenv("LIGDIFF_GEMM_TILE64"); return !(e != nullptr && e[0] == '0'); }();
+  const int64_t n = (int64_t)ceil_div(M, 128) * nb * chain_concurrent_calls();
+  return on && 2 * n <= device_cus();
+}
 // Split-operand mode (gemm4.h): while a cache is installed for the calling thread, the column-split
 // launches below convert each weight block they meet for the first time (one small launch on the
 // same stream) and run the bf16-pipe kernel; without a cache, or once its region is full, they run
@@ -110,6 +119,10 @@ static inline void launch_gemm_cs(const GemmCore& g, const AP& ap, const EPI& ep
     hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 4>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, sw, ap, epi);
     return;
   }
+  if (half_tiles(g.M, nb)) {
+    hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI, 4, 2>), dim3(ceil_div(g.M, 64), nb), dim3(256), 0, s, g, ap, epi);
+    return;
+  }
   hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);
 }
 // Four-wave row-slab launch for epilogues that need whole 128-column rows in one wave (operator() form):
@@ -131,6 +144,10 @@ static inline void launch_gemm_cs128(const GemmCore& g, const AP& ap, const EPI&
   SplitW sw;
   if (g_split != nullptr && split_blocks<2>(g, nb, s, &sw)) {
     hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, sw, ap, epi);
+    return;
+  }
+  if (half_tiles(g.M, nb)) {
+    hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI, 2, 2>), dim3(ceil_div(g.M, 64), nb), dim3(256), 0, s, g, ap, epi);
     return;
   }
   hipLaunchKernelGGL((gemm_cs_kernel<AP, EPI, 2>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, ap, epi);

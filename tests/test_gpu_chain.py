@@ -76,3 +76,16 @@ def test_chain_mode_switch_in_process():
     for a, b in ((x0, x2), (p0, p2)):
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 1e-4 * scale
+
+
+def test_half_tile_gemms_are_bitwise_the_full_tile_ones(tmp_path):
+    """Column-split GEMM launches of few rows run as 64-row workgroups (csrc/launch.h: half_tiles); a row's products
+    and sums are the same instructions in the same order as in the 128-row form, so every output of the separate-launch
+    path (forwards with ragged rows, properties, fully connected edges, and a sampling call) must agree bit for bit with
+    a process in which LIGDIFF_GEMM_TILE64=0 keeps the 128-row workgroups."""
+    half = _run(tmp_path, "half", {"LIGDIFF_CHAIN": "0"})
+    full = _run(tmp_path, "full", {"LIGDIFF_CHAIN": "0", "LIGDIFF_GEMM_TILE64": "0"})
+    assert set(half.files) == set(full.files)
+    for k in half.files:
+        assert np.isfinite(half[k]).all(), k
+        assert np.array_equal(half[k], full[k]), k
