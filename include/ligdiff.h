@@ -14,7 +14,7 @@
  *  - the concurrency hint (ligdiff_set_concurrent_calls) and the chain-kernel choice (ligdiff_set_chain_mode);
  *  - LIGDIFF_CFG_TWO_PASS (environment, read at every sampling call and workspace query);
  *  - A/B switches read once from the environment (LIGDIFF_GEMM_V1, LIGDIFF_GEMM_NOCS, LIGDIFF_CHAIN / LIGDIFF_NO_CHAIN, LIGDIFF_CHAIN_MOL,
- *    LIGDIFF_ATT_LDS,
+ *    LIGDIFF_ATT_LDS, LIGDIFF_GEMM_TILE64,
  *    LIGDIFF_ATT_BWD_V1, LIGDIFF_DW_BLOCKS);
  *  - the per-device scratch array of ligdiff_pack_csr_static.
  * HIP objects created and destroyed inside a call: ligdiff_ddpm_sample / ligdiff_ddim_sample with
