@@ -140,3 +140,103 @@ __global__ __launch_bounds__(128 * SLABS, 2) void gemm_cs_kernel(GemmCore g, AP 
   HalfMailbox mb{smem3 + 3 * ST, slab + 4 * half, lane};   // mailbox slots are numbered as in the 8-wave form
   epi.cs(acc, row_blk + slab * 32, by, half, lane, mb);
 }
+
+// 32-row form for launches of very few rows (at most one workgroup per CU): FOUR waves per 32-row slab, wave =
+// column half x column quarter, i.e. a 32 x 64 tile of two accumulators, so the chain of MFMAs a wave runs is half
+// that of the forms above and each wave has a SIMD to itself.  The epilogues want a wave to hold 128 columns of its
+// rows: after the K loop the second quarter of each half hands its two accumulators to the first through LDS and
+// ends; the first runs EPI::cs unchanged (a workgroup barrier inside an epilogue then joins the surviving waves
+// only).  An accumulator still receives the same MFMAs in the same order, so the results are bit for bit those of
+// gemm_cs_kernel.  Both waves of a quarter pair copy the slab's two A pieces (identical bytes to the same LDS
+// address) so that every wave issues five DMAs per chunk and one wait count serves all.
+template <class AP, class EPI>
+__global__ __launch_bounds__(256, 2) void gemm_cs_quarter_kernel(GemmCore g, AP ap, EPI epi) {
+  constexpr int A_FL = 32 * G2_ROWF;
+  constexpr int ST = (32 + 256) * G2_ROWF;
+  __shared__ __attribute__((aligned(1024))) float smemq[3 * ST + 4 * 256];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 1, quarter = wave & 1;
+  const int by = blockIdx.y;
+  const int row_blk = blockIdx.x * 32;
+  const float* __restrict__ W = g.W[by];
+
+  f32x16 acc[4];   // the wave's own tiles are acc[0], acc[1] until the hand-over
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+  const int pr = lane >> 2, ps = lane & 3;
+  const int lslot = ps ^ ((pr >> 2) & 3);
+  int a_row = row_blk + quarter * 16 + pr;
+  a_row = a_row < g.M ? a_row : g.M - 1;
+  const float* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int n = (wave * 4 + i) * 16 + pr;
+    n = n < g.n_valid ? n : g.n_valid - 1;
+    w_src[i] = W + (size_t)n * g.ldw + lslot * 4;
+  }
+  auto issue = [&](int kc, int buf) {
+    float* sA = smemq + buf * ST;
+    float* sW = sA + A_FL;
+    const int k0 = kc * G2_BK;
+    lds_dma16(ap.ptr(a_row, k0 + lslot * 4), sA + quarter * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_dma16(w_src[i] + k0, sW + (wave * 4 + i) * 256);
+  };
+
+  const int nk = g.K / G2_BK;
+  const int fi = lane & 31, hk = lane >> 5;
+  const int swz = (fi >> 2) & 3;
+  const int off0 = ((0 * 2 + hk) ^ swz) * 4, off1 = ((1 * 2 + hk) ^ swz) * 4;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  int cur = 0;
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) wait_vm_count<5>();
+    else wait_vm_count<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kc + 2 < nk) issue(kc + 2, cur == 0 ? 2 : cur - 1);
+    const float* sA = smemq + cur * ST;
+    const float* sW = sA + A_FL + (half * 128 + quarter * 64 + fi) * G2_ROWF;
+    const float* arow = sA + fi * G2_ROWF;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + off0);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + off1);
+    f32x4 b[2][2];
+    b[0][0] = *reinterpret_cast<const f32x4*>(sW + off0);
+    b[0][1] = *reinterpret_cast<const f32x4*>(sW + off1);
+    b[1][0] = *reinterpret_cast<const f32x4*>(sW + 32 * G2_ROWF + off0);
+    b[1][1] = *reinterpret_cast<const f32x4*>(sW + 32 * G2_ROWF + off1);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b[ct][0][j], acc[ct], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b[ct][1][j], acc[ct], 0, 0, 0);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  // hand-over through the stage area ([half][tile 2][register 16][lane 64] floats = 16 KiB), free once every wave
+  // has left the K loop
+  __syncthreads();
+  float* hand = smemq + half * (2 * 16 * 64);
+  if (quarter == 1) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hand[(ct * 16 + r) * 64 + lane] = acc[ct][r];
+  }
+  __syncthreads();
+  if (quarter == 1) return;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[2 + ct][r] = hand[(ct * 16 + r) * 64 + lane];
+  HalfMailbox mb{smemq + 3 * ST, 4 * half, lane};   // slots of slab 0 in the 8-wave numbering
+  epi.cs(acc, row_blk, by, half, lane, mb);
+}

@@ -76,6 +76,13 @@ static inline bool half_tiles(int M, int nb) {
   const int64_t n = (int64_t)ceil_div(M, 128) * nb * chain_concurrent_calls();
   return on && 2 * n <= device_cus();
 }
+// Launches of very few rows: with at most one 32-row workgroup per CU the four-wave 32-row form (gemm_cs_quarter_kernel)
+// halves the chain of MFMAs a wave runs once more.  Same bits, same switch.
+static inline bool quarter_tiles(int M, int nb) {
+  static const bool on = [] { const char* e = getenv("LIGDIFF_GEMM_TILE64"); return !(e != nullptr && e[0] == '0'); }();
+  const int64_t n = (int64_t)ceil_div(M, 32) * nb * chain_concurrent_calls();
+  return on && n <= device_cus();
+}
 // Split-operand mode (gemm4.h): while a cache is installed for the calling thread, the column-split
 // launches below convert each weight block they meet for the first time (one small launch on the
 // same stream) and run the bf16-pipe kernel; without a cache, or once its region is full, they run
@@ -117,6 +124,10 @@ static inline void launch_gemm_cs(const GemmCore& g, const AP& ap, const EPI& ep
   SplitW sw;
   if (g_split != nullptr && split_blocks<4>(g, nb, s, &sw)) {
     hipLaunchKernelGGL((gemm_cs_split_kernel<AP, EPI, 4>), dim3(ceil_div(g.M, 128), nb), dim3(512), 0, s, g, sw, ap, epi);
+    return;
+  }
+  if (quarter_tiles(g.M, nb)) {
+    hipLaunchKernelGGL((gemm_cs_quarter_kernel<AP, EPI>), dim3(ceil_div(g.M, 32), nb), dim3(256), 0, s, g, ap, epi);
     return;
   }
   if (half_tiles(g.M, nb)) {
