@@ -69,12 +69,16 @@ static inline bool use_chain(int64_t rows) {
 }
 // Column-split GEMM launches of few rows: a 128-row workgroup is eight waves, two to a SIMD, and a wave's tile is a
 // fixed chain of MFMAs, so a launch whose 128-row workgroups cover at most half of the CUs runs as 64-row
-// workgroups (four waves, one to a SIMD, on twice as many CUs) in about half the time.  Same bits either way
+// workgroups (four waves, one to a SIMD, on twice as many CUs) in about half the time (2n <= CUs is the first case
+// of the rule below).  Same bits either way
 // (LIGDIFF_GEMM_TILE64=0 switches the choice off for A/B runs).
 static inline bool half_tiles(int M, int nb) {
   static const bool on = [] { const char* e = getenv("LIGDIFF_GEMM_TILE64"); return !(e != nullptr && e[0] == '0'); }();
-  const int64_t n = (int64_t)ceil_div(M, 128) * nb * chain_concurrent_calls();
-  return on && 2 * n <= device_cus();
+  const int64_t n = (int64_t)ceil_div(M, 128) * nb * chain_concurrent_calls(), cu = device_cus();
+  // also at larger sizes whenever the finer grain lowers the most waves a SIMD gets: ceil(2n / CUs) four-wave
+  // workgroups on the fullest CU against ceil(n / CUs) eight-wave ones (measured: reverse step 1.49 -> 1.44 ms at
+  // 400 ligands of 29 atoms, 1.54 -> 1.50 at 512; training step 8.0 -> 7.7 ms at 400, 10.7 -> 10.4 at 600)
+  return on && (2 * n + cu - 1) / cu < 2 * ((n + cu - 1) / cu);
 }
 // Launches of very few rows: with at most one 32-row workgroup per CU the four-wave 32-row form (gemm_cs_quarter_kernel)
 // halves the chain of MFMAs a wave runs once more.  Same bits, same switch.
