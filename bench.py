@@ -64,29 +64,33 @@ def spawn_ranks(args, passthrough):
 
 
 # ------------------------------------------------------------------ counters from the committed profile
-def profile_traffic():
-    """HBM-side bytes per launch from the newest committed rocprofv3 PMC summary
-    (profiles/r*_pmc_summary.csv: per-kernel means of FETCH_SIZE and WRITE_SIZE in KB, taken in
-    separate passes).  On gfx950 FETCH_SIZE counts half the bytes of a wide streaming read, so
-    read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.  The counters cannot be read from inside this
-    process; a kernel that the summary does not list gets None."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")))
-    files = [f for f in files if "split" not in os.path.basename(f)]
-    fwd = [f for f in files if "train" not in os.path.basename(f)]
-    trn = [f for f in files if "train" in os.path.basename(f)]
-    out, used = {}, []
-    # the training-step passes first, then the forward passes on top: a kernel that both list
-    # takes the forward-only figure (the sampling shape)
-    for path in ([trn[-1]] if trn else []) + ([fwd[-1]] if fwd else []):
-        vals = {}
-        with open(path) as fh:
-            for row in csv.DictReader(fh):
-                vals.setdefault(row["Kernel_Name"], {})[row["Counter_Name"]] = float(row["Mean_Counter_Value_KB"])
-        for name, c in vals.items():
-            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                out[name] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-        used.append(os.path.relpath(path, ROOT))
-    return out, (" + ".join(used) if used else None)
+def profile_traffic(shape="headline"):
+    """HBM-side bytes per launch from the newest committed rocprofv3 PMC summary taken at ``shape``
+    (profiles/r<round>_<letter>[_<shape>]_pmc_summary.csv: per-kernel means of FETCH_SIZE and WRITE_SIZE in KB,
+    taken in separate passes; no shape tag = the headline shape, 1024 x 29-atom template ligands; "train" the training
+    step at that shape; "fc", "train3", "ragged5" the shapes of the extra legs, tools/pmc_shape.py).  On gfx950
+    FETCH_SIZE counts half the bytes of a wide streaming read, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.
+    The counters cannot be read from inside this process; a kernel that the summary does not list gets None.
+    Returns (table, file name or None)."""
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")):
+        m = re.fullmatch(r"r(\d+)_([a-z])(?:_(\w+?))?_pmc_summary\.csv", os.path.basename(path))
+        if m is None or (m.group(3) or "headline") != shape:
+            continue
+        key = (int(m.group(1)), m.group(2))
+        if best is None or key > best[0]:
+            best = (key, path)
+    if best is None:
+        return {}, None
+    vals, out = {}, {}
+    with open(best[1]) as fh:
+        for row in csv.DictReader(fh):
+            vals.setdefault(row["Kernel_Name"], {})[row["Counter_Name"]] = float(row["Mean_Counter_Value_KB"])
+    for name, c in vals.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            out[name] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    return out, os.path.relpath(best[1], ROOT)
 
 
 def traffic_of(table, *needles):
@@ -579,9 +583,12 @@ def run_rank(args):
             print(json.dumps(line), flush=True)
 
     def watchdog():
+        # a stuck leg or collective: the measured headline still goes out, but the run is reported as failed
         emit(f"extra legs abandoned after {EXTRAS_BUDGET_S:.0f} s")
         sys.stdout.flush()
-        os._exit(0)
+        print(f"bench.py: extra legs did not return within {EXTRAS_BUDGET_S:.0f} s; exiting with status 3", file=sys.stderr,
+              flush=True)
+        os._exit(3)
 
     if args.no_extras:
         emit()

@@ -39,6 +39,31 @@ class Dropout(C.Structure):
                 ("p_ffn_hidden", C.c_float * 3), ("p_ffn_out", C.c_float * 3), ("p_consistency", C.c_float * 2)]
 
 
+class Options(C.Structure):
+    """struct ligdiff_options: per-call choices (-1, or 0 for concurrent_calls, = not set)."""
+    _fields_ = [("gemm_mode", C.c_int32), ("chain_mode", C.c_int32), ("concurrent_calls", C.c_int32),
+                ("edge_chain", C.c_int32), ("node_chain", C.c_int32), ("mol_wave", C.c_int32),
+                ("edge_reduce", C.c_int32), ("cfg_two_pass", C.c_int32)]
+
+    def __init__(self, **fields):
+        super().__init__()
+        for name, _ in self._fields_:
+            setattr(self, name, 0 if name == "concurrent_calls" else -1)
+        for k, v in fields.items():
+            if k not in dict(self._fields_):
+                raise TypeError(f"ligdiff_options has no field {k}")
+            setattr(self, k, int(v))
+
+    def copy(self, **fields):
+        out = Options(**{name: getattr(self, name) for name, _ in self._fields_})
+        for k, v in fields.items():
+            setattr(out, k, int(v))
+        return out
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
 class LossArgs(C.Structure):
     """struct ligdiff_loss_args"""
     _fields_ = [("pos", C.c_void_p), ("noise", C.c_void_p), ("noisy", C.c_void_p), ("coef", C.c_void_p),
@@ -70,6 +95,28 @@ SIGNATURES = {
     "ligdiff_backward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.POINTER(Dropout)]),
+    "ligdiff_options_init": (None, [C.POINTER(Options)]),
+    "ligdiff_plan": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.POINTER(Options), C.POINTER(Options)]),
+    "ligdiff_forward_workspace_bytes_opt": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int, C.POINTER(Options)]),
+    "ligdiff_forward_opt": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.POINTER(Dropout), C.POINTER(Options)]),
+    "ligdiff_forward_timed_opt": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(Options)]),
+    "ligdiff_backward_workspace_bytes_opt": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.POINTER(Options)]),
+    "ligdiff_backward_opt": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.POINTER(Dropout), C.POINTER(Options)]),
+    "ligdiff_ddpm_sample_opt": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.POINTER(Options)]),
+    "ligdiff_ddpm_sample_workspace_bytes_opt": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int, C.c_int32,
+                                                             C.POINTER(Options)]),
+    "ligdiff_ddim_sample_opt": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.POINTER(Options)]),
     "ligdiff_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "ligdiff_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "ligdiff_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p,

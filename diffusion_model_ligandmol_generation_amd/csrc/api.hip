@@ -71,6 +71,39 @@ extern "C" int ligdiff_forward_train(const float* const* weights, const ligdiff_
                      (char*)workspace, (hipStream_t)stream, nullptr, nullptr, dropout);
 }
 
+extern "C" size_t ligdiff_forward_workspace_bytes_opt(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int flags,
+                                                      const ligdiff_options* options) {
+  if (check_options(options)) return 0;
+  CallOptions scope(options);
+  return ligdiff_forward_workspace_bytes(n_atoms, n_edges, n_mols, flags);
+}
+extern "C" int ligdiff_forward_opt(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                                   const float* pos, const float* t, const int32_t* t_index_dev,
+                                   const float* properties, int flags, float* atom_pred, float* pos_pred,
+                                   float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
+                                   const ligdiff_dropout* dropout, const ligdiff_options* options) {
+  if (check_options(options)) return LIGDIFF_ERR_ARG;
+  CallOptions scope(options);
+  return ligdiff_forward_train(weights, graph, x, pos, t, t_index_dev, properties, flags, atom_pred, pos_pred, prop_pred,
+                               workspace, workspace_bytes, stream, dropout);
+}
+extern "C" int ligdiff_forward_timed(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                                     const float* pos, const float* t, const int32_t* t_index_dev,
+                                     const float* properties, int flags, float* atom_pred, float* pos_pred,
+                                     float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
+                                     const char* label, int32_t reps, float* mean_ms_host);
+extern "C" int ligdiff_forward_timed_opt(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                                         const float* pos, const float* t, const int32_t* t_index_dev,
+                                         const float* properties, int flags, float* atom_pred, float* pos_pred,
+                                         float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
+                                         const char* label, int32_t reps, float* mean_ms_host,
+                                         const ligdiff_options* options) {
+  if (check_options(options)) return LIGDIFF_ERR_ARG;
+  CallOptions scope(options);
+  return ligdiff_forward_timed(weights, graph, x, pos, t, t_index_dev, properties, flags, atom_pred, pos_pred, prop_pred,
+                               workspace, workspace_bytes, stream, label, reps, mean_ms_host);
+}
+
 extern "C" int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, const float* x,
                                const float* pos, const float* t, const int32_t* t_index_dev,
                                const float* properties, int flags, float* atom_pred, float* pos_pred,

@@ -478,6 +478,23 @@ extern "C" int ligdiff_backward(const float* const* w, float* const* gr, const l
                                 workspace_bytes, stream, nullptr);
 }
 
+extern "C" size_t ligdiff_backward_workspace_bytes_opt(int64_t n_atoms, int64_t n_edges, int32_t n_mols,
+                                                       const ligdiff_options* options) {
+  if (check_options(options)) return 0;
+  CallOptions scope(options);
+  return ligdiff_backward_workspace_bytes(n_atoms, n_edges, n_mols);
+}
+extern "C" int ligdiff_backward_opt(const float* const* w, float* const* gr, const ligdiff_graph* g, const float* x,
+                                    const float* pos, const float* properties, int flags, const float* d_atom,
+                                    const float* d_pos, const float* d_prop, const void* fwd_workspace,
+                                    void* workspace, size_t workspace_bytes, void* stream,
+                                    const ligdiff_dropout* dropout, const ligdiff_options* options) {
+  if (check_options(options)) return LIGDIFF_ERR_ARG;
+  CallOptions scope(options);
+  return ligdiff_backward_train(w, gr, g, x, pos, properties, flags, d_atom, d_pos, d_prop, fwd_workspace, workspace,
+                                workspace_bytes, stream, dropout);
+}
+
 // Measurement hook for bench.py: runs `reps` backward passes (gradients keep accumulating into
 // `gr`: give it throw-away buffers) and returns the mean duration, from HIP events on `stream` net of
 // an empty event pair, of the `wide_dw_index`-th gemm_dw_kernel<4> launch of a pass, with its

@@ -18,6 +18,10 @@ struct EdgeChainArgs {
   float* msg;                // [E,256]
   float* wrel;               // [E,4] (components 0..2 written)
   unsigned long long* stamps;   // diagnostic builds (DBG): [grid][8] shader-clock stamps of wave 0
+  float* part;               // REDUCE form: [N + slabs, 256] per-slab partial sums instead of msg (see edge_chain.h)
+  const int32_t* slab_e0;    // REDUCE form: first edge / edge count (<= 32) of every slab; n_slabs entries, the ones
+  const int32_t* slab_cnt;   //   past the last molecule's slabs hold (0, 0)
+  int n_slabs;               // REDUCE form: table length = grid size * 4
 };
 
 enum { NODE_TAIL_NONE = 0, NODE_TAIL_PROJ = 1, NODE_TAIL_QKV = 2 };
@@ -57,6 +61,6 @@ struct DitChainArgs {
 };
 
 // One launch each on stream s; grids follow from the argument blocks.
-void launch_edge_chain(const EdgeChainArgs& a, hipStream_t s);                              // ceil(E / 128) workgroups
+void launch_edge_chain(const EdgeChainArgs& a, hipStream_t s);                              // ceil(E / 128) workgroups; a.part != NULL: REDUCE form, n_slabs / 4
 void launch_node_chain(const NodeChainArgs& a, int tail, hipStream_t s);                    // ceil(M / 128) workgroups
 void launch_dit_chain(const DitChainArgs& a, int tail, bool mol_wave, hipStream_t s);       // ceil(M / 128), or ceil(B / 4) in the molecule-per-wave form

@@ -14,7 +14,18 @@
 #include "chain_args.h"
 
 
-template <bool DBG = false, int ABL = 0>   // ABL: timing ablations (developer switch; results are wrong when non-zero)
+//
+// REDUCE (graphs of high in-degree): msg never reaches memory.  The edges are in CSR order, so the rows of one
+// destination atom are consecutive; after the coordinate gate every wave lays its 32 x 256 msg tile out in LDS (the
+// weight ring is free by then, 32 KiB per wave), lane l sums features 4l .. 4l + 3 over the rows of each destination
+// in edge order, and the sum of destination a inside slab s goes to row a + s of `part`.  (a, s) -> a + s is
+// one-to-one because a does not decrease with s, and the rows of one atom are consecutive: the aggregation kernel
+// adds rows a + s_first .. a + s_last.  A 127-edge destination leaves 4-5 partial rows instead of 127 message rows.
+// In this form a wave's slab is 32 consecutive edges of ONE molecule counted from the molecule's first edge (table
+// slab_e0 / slab_cnt, built by k_slab_scan / k_slab_fill; a molecule's last slab may be short), so how an atom's
+// messages are grouped into partial sums - and with it every bit of the result - depends on the molecule alone, not
+// on what precedes it in the batch.
+template <bool DBG = false, int ABL = 0, bool REDUCE = false>   // ABL: timing ablations (developer switch; results are wrong when non-zero)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void edge_chain_kernel(EdgeChainArgs p) {
   __shared__ __attribute__((aligned(1024))) float smem[4 * CH_TILE_FL + 1024];
@@ -37,8 +48,19 @@ void edge_chain_kernel(EdgeChainArgs p) {
   for (int n = 0; n < 8; ++n) cl.dma_tall(p.W2, 256, 32, ring + CH_TILE_FL, n);
   // prologue loads: the edge's end points first (the P gathers depend on them), everything else behind them, the LDS
   // write of the small vectors last, so that the wave waits for memory twice (indices, then the rest) and not four times
-  const int e_raw = blockIdx.x * 128 + cl.wave * 32 + fi;
-  const int e = e_raw < p.E ? e_raw : p.E - 1;
+  int e_raw, e;
+  bool valid;
+  if constexpr (REDUCE) {
+    const int slab = blockIdx.x * 4 + cl.wave;
+    const int e_lo = p.slab_e0[slab];
+    e_raw = e_lo + fi;
+    valid = fi < p.slab_cnt[slab];
+    e = valid ? e_raw : e_lo;   // (an unused slab has e_lo = 0, count 0: its lanes recompute edge 0 and store nothing)
+  } else {
+    e_raw = blockIdx.x * 128 + cl.wave * 32 + fi;
+    valid = e_raw < p.E;
+    e = valid ? e_raw : p.E - 1;
+  }
   const int i_src = p.src[e], i_dst = p.dst[e];
   const float* svp = tid < 64 ? p.b2 + tid * 4 : tid < 128 ? p.gamma + (tid - 64) * 4
                    : tid < 192 ? p.beta + (tid - 128) * 4 : tid < 224 ? p.bc1 + (tid - 192) * 4 : p.wc2 + (tid - 224) * 4;
@@ -176,7 +198,7 @@ void edge_chain_kernel(EdgeChainArgs p) {
         [&](auto) -> f32x16& { return hid; },
         [&](auto J) {   // the first step stores msg, one 16-byte piece per group
           constexpr int j = decltype(J)::value;
-          if (c == 0 && e_raw < p.E)
+          if (!REDUCE && c == 0 && valid)
             *reinterpret_cast<f32x4*>(mrow + 8 * j) =
                 f32x4{msg[j >> 2][4 * (j & 3)], msg[j >> 2][4 * (j & 3) + 1], msg[j >> 2][4 * (j & 3) + 2], msg[j >> 2][4 * (j & 3) + 3]};
           if (c == 1 && j < 8) cl.dma_wide(p.Wc1, 256, 96, 128, 0, ring + (11 % 3) * CH_TILE_FL, j);   // Wc1 tile 3
@@ -190,9 +212,36 @@ void edge_chain_kernel(EdgeChainArgs p) {
   stamp(4);
   cs += __shfl_xor(cs, 32);
   const float cw = tanhf(cs + bc2);
-  if (h == 0 && e_raw < p.E) {
+  if (h == 0 && valid) {
     float* wr = p.wrel + (size_t)e * 4;
     wr[0] = relv[0] * cw; wr[1] = relv[1] * cw; wr[2] = relv[2] * cw;
   }
   stamp(5);
+  if constexpr (REDUCE) {
+    __syncthreads();   // every wave has finished its last weight tile: the four 32-KiB buffers are free
+    float* const tile = smem + cl.wave * CH_TILE_FL;   // [32 edges][64 slots of 16 B], slot ^ (edge & 15)
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(tile + fi * 256 + (((8 * o + 2 * g + h) ^ (fi & 15)) << 2)) =
+            f32x4{msg[o][4 * g], msg[o][4 * g + 1], msg[o][4 * g + 2], msg[o][4 * g + 3]};
+    const int dst_l = valid ? i_dst : -1;
+    const int slab = blockIdx.x * 4 + cl.wave;
+    int cur = -1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const int d = __builtin_amdgcn_readlane(dst_l, r);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * 256 + ((cl.lane ^ (r & 15)) << 2));
+      if (d != cur) {   // wave-uniform: a new destination starts at row r
+        if (cur >= 0) *reinterpret_cast<f32x4*>(p.part + (size_t)(slab + cur) * 256 + cl.lane * 4) = acc;
+        acc = v;
+        cur = d;
+      } else {
+        acc += v;
+      }
+    }
+    if (cur >= 0) *reinterpret_cast<f32x4*>(p.part + (size_t)(slab + cur) * 256 + cl.lane * 4) = acc;
+  }
 }

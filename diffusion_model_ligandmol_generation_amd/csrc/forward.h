@@ -17,6 +17,9 @@ struct FwdLayout {
   size_t pos_upd, pos_cur;          // [N,3]
   size_t P[3], rel[3], rbf[3], a1[3], msg[3], wrel[3], agg[3], hid[3], h_e3[3];
   size_t xn1[3], qkv[3], att[3], x1[3], xn2[3], ffh[3], x2[3];
+  size_t mol_e0, mol_slab0;         // [B+1] int32: first edge / first slab of each molecule (REDUCE form of the edge kernel)
+  size_t slab_e0, slab_cnt;         // [n_slab_cap] int32: first edge / edge count of each slab
+  int64_t n_slab_cap;               // slabs the tables hold: a multiple of 4 >= E / 32 + B
   size_t yh;                        // [N,512] head hidden (atom | pos)
   size_t pooled, ph;                // [B,256]
   // kept only with LIGDIFF_FWD_SAVE_FOR_BACKWARD (pre-activations the backward pass needs)
@@ -27,7 +30,23 @@ struct FwdLayout {
   size_t wsplit, wsplit_bytes;      // split-bf16 copies of the GEMM weights (split-operand mode only, else 0 bytes)
   size_t total;
 };
-// Split-operand GEMM mode of the forward pass (process-wide; see ligdiff_set_split_gemm).
+// Per-call options (ligdiff_options): an *_opt entry point installs the caller's struct for the calling thread for
+// the duration of the call; every choice below looks there first and at the process-wide defaults second.
+struct CallOptions {
+  const ligdiff_options* prev;
+  explicit CallOptions(const ligdiff_options* o);
+  ~CallOptions();
+};
+const ligdiff_options* call_options();
+int check_options(const ligdiff_options* o);   // LIGDIFF_OK or LIGDIFF_ERR_ARG (a field out of range)
+// Which forms the inference path takes for a launch set of these sizes: the call's options where they say, the
+// fill / in-degree rules of launch.h where they do not.  "Wanted" only: run_forward still checks what each form
+// needs (aligned weights, shared timestep, no saved activations, fp32 pipe, molecule sizes).
+struct FwdPlan { bool edge_chain, node_chain, mol_wave, edge_reduce; };
+FwdPlan forward_plan(int64_t n_atoms, int64_t n_edges, int64_t n_mols, int max_mol_atoms);
+// True when guided sampling runs the conditional and unconditional batch as one doubled forward.
+bool cfg_one_pass();
+// Split-operand GEMM mode of the calling thread's current call (see ligdiff_set_split_gemm / ligdiff_options).
 bool split_gemm_enabled();
 // True unless an environment A/B switch routed the GEMMs to the register-staged kernels.
 bool fwd_column_split_gemms();

@@ -116,10 +116,28 @@ const WeightInfo* weight_table() {
 
 #include "launch.h"
 
-// ------------------------------------------------------------------ split-operand mode
+// ------------------------------------------------------------------ per-call options and process-wide defaults
 #include <atomic>
+static thread_local const ligdiff_options* t_options = nullptr;
+CallOptions::CallOptions(const ligdiff_options* o) : prev(t_options) { t_options = o; }
+CallOptions::~CallOptions() { t_options = prev; }
+const ligdiff_options* call_options() { return t_options; }
+extern "C" void ligdiff_options_init(ligdiff_options* o) {
+  if (o == nullptr) return;
+  o->gemm_mode = -1; o->chain_mode = -1; o->concurrent_calls = 0;
+  o->edge_chain = -1; o->node_chain = -1; o->mol_wave = -1; o->edge_reduce = -1; o->cfg_two_pass = -1;
+}
+int check_options(const ligdiff_options* o) {
+  if (o == nullptr) return LIGDIFF_OK;
+  auto tri = [](int v) { return v >= -1 && v <= 1; };
+  if (!tri(o->gemm_mode) || o->chain_mode < -1 || o->chain_mode > 2 || o->concurrent_calls < 0 || o->concurrent_calls > 16 ||
+      !tri(o->edge_chain) || !tri(o->node_chain) || !tri(o->mol_wave) || !tri(o->edge_reduce) || !tri(o->cfg_two_pass))
+    return LIGDIFF_ERR_ARG;
+  return LIGDIFF_OK;
+}
 static std::atomic<int> g_split_mode{-1};   // -1: not decided yet (environment), 0 / 1
 bool split_gemm_enabled() {
+  if (t_options != nullptr && t_options->gemm_mode >= 0) return t_options->gemm_mode != 0;
   int m = g_split_mode.load(std::memory_order_relaxed);
   if (m < 0) {
     const char* e = getenv("LIGDIFF_GEMM_SPLIT");
@@ -129,22 +147,61 @@ bool split_gemm_enabled() {
   return m != 0;
 }
 bool fwd_column_split_gemms() { return use_cs(); }
+bool cfg_one_pass() {   // the environment is read per call: the tests flip it within one process
+  if (!use_cs()) return false;
+  if (t_options != nullptr && t_options->cfg_two_pass >= 0) return t_options->cfg_two_pass == 0;
+  return getenv("LIGDIFF_CFG_TWO_PASS") == nullptr;
+}
 static std::atomic<int> g_chain_mode{-1};
-int chain_mode_override() { return g_chain_mode.load(std::memory_order_relaxed); }
+int chain_mode_override() {
+  if (t_options != nullptr && t_options->chain_mode >= 0) return t_options->chain_mode;
+  return g_chain_mode.load(std::memory_order_relaxed);
+}
 extern "C" int ligdiff_set_chain_mode(int mode) {
   if (mode < -1 || mode > 2) return -2;
   return g_chain_mode.exchange(mode, std::memory_order_relaxed);
 }
 static std::atomic<int> g_concurrent_calls{1};
-int chain_concurrent_calls() { return g_concurrent_calls.load(std::memory_order_relaxed); }
+int chain_concurrent_calls() {
+  if (t_options != nullptr && t_options->concurrent_calls > 0) return t_options->concurrent_calls;
+  return g_concurrent_calls.load(std::memory_order_relaxed);
+}
 extern "C" int ligdiff_set_concurrent_calls(int k) {
   if (k < 1 || k > 16) return -1;
   return g_concurrent_calls.exchange(k, std::memory_order_relaxed);
 }
 extern "C" int ligdiff_set_split_gemm(int enabled) {
-  const int prev = split_gemm_enabled() ? 1 : 0;
+  int m = g_split_mode.load(std::memory_order_relaxed);
+  if (m < 0) {   // the process default, whatever options the calling thread may have installed
+    const char* e = getenv("LIGDIFF_GEMM_SPLIT");
+    m = (e != nullptr && e[0] != '\0' && e[0] != '0') ? 1 : 0;
+  }
   g_split_mode.store(enabled ? 1 : 0, std::memory_order_relaxed);
-  return prev;
+  return m;
+}
+FwdPlan forward_plan(int64_t N, int64_t E, int64_t B, int max_mol_atoms) {
+  const ligdiff_options* o = t_options;
+  auto pick = [](int field, bool by_rule) { return field >= 0 ? field != 0 : by_rule; };
+  FwdPlan p;
+  p.edge_chain = pick(o ? o->edge_chain : -1, use_chain(E));
+  p.node_chain = pick(o ? o->node_chain : -1, use_chain(N));
+  // molecules of at most 32 atoms that fill at least three quarters of a 32-lane slab each
+  p.mol_wave = pick(o ? o->mol_wave : -1, chain_mol_allowed() && max_mol_atoms <= 32 && 4 * N >= 3 * 32 * B && use_chain(32 * B));
+  p.edge_reduce = pick(o ? o->edge_reduce : -1, edge_reduce_wanted(N, E));
+  return p;
+}
+extern "C" int ligdiff_plan(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int32_t max_mol_atoms,
+                            const ligdiff_options* in, ligdiff_options* out) {
+  if (out == nullptr || n_atoms <= 0 || n_edges < 0 || n_mols <= 0 || max_mol_atoms <= 0 || check_options(in)) return LIGDIFF_ERR_ARG;
+  ligdiff_options r;
+  if (in != nullptr) r = *in; else ligdiff_options_init(&r);
+  {
+    CallOptions scope(&r);
+    const FwdPlan p = forward_plan(n_atoms, n_edges, n_mols, max_mol_atoms);
+    r.edge_chain = p.edge_chain; r.node_chain = p.node_chain; r.mol_wave = p.mol_wave; r.edge_reduce = p.edge_reduce;
+  }
+  *out = r;
+  return LIGDIFF_OK;
 }
 // Bytes reserved for the split weight copies: 6 bytes per weight element plus room for blocks whose
 // rows are zero-extended to the 128 / 256 columns of a block (a full region falls back to the fp32 pipe).
@@ -253,6 +310,9 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
   per_layer(L->xn1, N * 256); per_layer(L->qkv, N * 768); per_layer(L->att, N * 256);
   per_layer(L->xn2, N * 256); per_layer(L->ffh, N * 1024);
   stream_buf(L->h_e3); stream_buf(L->x1); stream_buf(L->x2);
+  L->n_slab_cap = ((E + 31) / 32 + B + 3) / 4 * 4;
+  L->mol_e0 = take((size_t)B + 1); L->mol_slab0 = take((size_t)B + 1);
+  L->slab_e0 = take((size_t)L->n_slab_cap); L->slab_cnt = take((size_t)L->n_slab_cap);
   L->yh = take(N * 512);
   L->pooled = take((size_t)B * 256); L->ph = take((size_t)B * 256);
   L->save = save ? 1 : 0;
@@ -433,17 +493,30 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   // (their vector loads and LDS-DMAs need 16-byte aligned weight tensors)
   bool w_aligned = true;
   for (int i = 0; i < W_CONS_0; ++i) w_aligned = w_aligned && (w[i] == nullptr || (reinterpret_cast<uintptr_t>(w[i]) & 15) == 0);
-  const bool edge_chain = w_aligned && use_chain(E) && !L.save && g_split == nullptr && E > 0 && (int64_t)N * 512 < (1LL << 31);
+  const FwdPlan plan = forward_plan(N, E, B, g->max_mol_atoms);
+  const bool edge_chain = w_aligned && plan.edge_chain && !L.save && g_split == nullptr && E > 0 && (int64_t)N * 512 < (1LL << 31);
+  // graphs of high in-degree (fully connected ligands): the fused edge kernel sums each destination's messages per
+  // 32-edge slab itself and the [E,256] message tensor never reaches memory; the partial sums take the message
+  // buffer's place (at most N + E / 32 + B + 3 rows, so the form needs E >= that)
+  const bool edge_reduce = edge_chain && plan.edge_reduce && (int64_t)N + L.n_slab_cap <= (int64_t)E;
   // likewise the node update of a layer together with what follows it (the next layer's per-node edge
   // projections, or the first attention layer's pre-norm and in-projection), and everything between two
   // attention kernels (out-projection, feed-forward block, the next layer's pre-norm and in-projection)
-  const bool node_chain = w_aligned && use_chain(N) && !L.save && g_split == nullptr && N > 0;
+  const bool node_chain = w_aligned && plan.node_chain && !L.save && g_split == nullptr && N > 0;
   // (the node and attention-layer kernels stage ONE adaLN row: calls whose molecules share the timestep)
   const bool dit_chain = node_chain && drop == nullptr && mstride == 0;
-  // molecules of at most 32 atoms that fill at least three quarters of a 32-lane slab each: one molecule per wave,
-  // attention inside the attention-layer kernel (no attention launches, no qkv in memory)
-  const bool mol_wave = dit_chain && chain_mol_allowed() && g->max_mol_atoms <= 32 && 4 * (int64_t)N >= 3 * 32 * (int64_t)B &&
-                        use_chain(32 * (int64_t)B);
+  // one molecule per wave, attention inside the attention-layer kernel (no attention launches, no qkv in memory)
+  const bool mol_wave = dit_chain && plan.mol_wave && g->max_mol_atoms <= 32;
+  int32_t* const mol_e0 = reinterpret_cast<int32_t*>(ws + L.mol_e0);
+  int32_t* const mol_slab0 = reinterpret_cast<int32_t*>(ws + L.mol_slab0);
+  int32_t* const slab_e0 = reinterpret_cast<int32_t*>(ws + L.slab_e0);
+  int32_t* const slab_cnt = reinterpret_cast<int32_t*>(ws + L.slab_cnt);
+  if (edge_reduce) {   // molecule-aligned 32-edge slabs, the same for the three layers
+    const int cap = (int)L.n_slab_cap;
+    hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(1024), 0, s, g->mol_ptr, g->dst_ptr, B, mol_e0, mol_slab0);
+    hipLaunchKernelGGL(k_slab_fill, dim3(ceil_div(B, 4) + ceil_div(cap, 256)), dim3(256), 0, s, mol_e0, mol_slab0, B, cap,
+                       slab_e0, slab_cnt);
+  }
   for (int l = 0; l < 3; ++l) {
     const float* pos_l = (l == 0) ? pos : F(L.pos_cur);
     // per-node halves of the first edge linear: P = h [W1a | W1b]^T
@@ -485,6 +558,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         ea.W2 = w[W_E3(l, E3_EN2_W)]; ea.b2 = w[W_E3(l, E3_EN2_B)]; ea.gamma = w[W_E3(l, E3_EN3_G)]; ea.beta = w[W_E3(l, E3_EN3_B)];
         ea.Wc1 = w[W_E3(l, E3_CN0_W)]; ea.bc1 = w[W_E3(l, E3_CN0_B)]; ea.wc2 = w[W_E3(l, E3_CN2_W)]; ea.bc2 = w[W_E3(l, E3_CN2_B)];
         ea.msg = F(L.msg[l]); ea.wrel = F(L.wrel[l]);
+        if (edge_reduce) { ea.part = F(L.msg[l]); ea.slab_e0 = slab_e0; ea.slab_cnt = slab_cnt; ea.n_slabs = (int)L.n_slab_cap; }
         PB("e3_%d.edge_chain", l);
         launch_edge_chain(ea, s);
         PE();
@@ -526,9 +600,14 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       }
     }
     PB("e3_%d.aggregate", l);
-    hipLaunchKernelGGL(k_aggregate, dim3(ceil_div(N, 8)), dim3(256), 0, s, F(L.msg[l]), F(L.wrel[l]), g->dst_ptr,
-                       g->src_ptr, g->src_slot, pos, F(L.pos_upd), F(L.pos_cur), F(L.agg[l]), (float*)nullptr, N,
-                       l == 0 ? 1 : 0);
+    if (edge_reduce)
+      hipLaunchKernelGGL(k_aggregate<true>, dim3(ceil_div(N, 8)), dim3(256), 0, s, F(L.msg[l]), F(L.wrel[l]), g->dst_ptr,
+                         g->src_ptr, g->src_slot, pos, F(L.pos_upd), F(L.pos_cur), F(L.agg[l]), (float*)nullptr, N,
+                         l == 0 ? 1 : 0, g->atom_mol, mol_e0, mol_slab0);
+    else
+      hipLaunchKernelGGL(k_aggregate<false>, dim3(ceil_div(N, 8)), dim3(256), 0, s, F(L.msg[l]), F(L.wrel[l]), g->dst_ptr,
+                         g->src_ptr, g->src_slot, pos, F(L.pos_upd), F(L.pos_cur), F(L.agg[l]), (float*)nullptr, N,
+                         l == 0 ? 1 : 0);
     PE();
     if (node_chain) {
       NodeChainArgs na;

@@ -160,12 +160,17 @@ __global__ __launch_bounds__(256) void k_pos_embed(const float* __restrict__ pos
 // Two atoms per wave (one per 32-lane half, 32 B of every row per lane) and all four CSR
 // bounds loaded up front: an atom has ~2 incoming edges, so the kernel is a chain of three
 // dependent memory latencies and its rate is set by how many of them are in flight.
+// PARTS: `msg` holds the per-slab partial sums of the fused edge kernel's REDUCE form (edge_chain.h) instead of
+// message rows: atom i adds rows i + slab(e0) .. i + slab(e1 - 1), in that order, where slab(e) counts 32-edge slabs
+// from the first edge of the atom's molecule: mol_slab0[m] + ((e - mol_e0[m]) >> 5).
+template <bool PARTS = false>
 __global__ __launch_bounds__(256) void k_aggregate(
     const float* __restrict__ msg, const float* __restrict__ wrel,
     const int32_t* __restrict__ dst_ptr, const int32_t* __restrict__ src_ptr,
     const int32_t* __restrict__ src_slot, const float* __restrict__ pos,
     float* __restrict__ pos_upd, float* __restrict__ pos_cur, float* __restrict__ agg,
-    float* __restrict__ dpos_out, int N, int first_layer) {
+    float* __restrict__ dpos_out, int N, int first_layer, const int32_t* __restrict__ atom_mol = nullptr,
+    const int32_t* __restrict__ mol_e0 = nullptr, const int32_t* __restrict__ mol_slab0 = nullptr) {
   const int l = threadIdx.x & 31;
   const int node = blockIdx.x * 8 + (threadIdx.x >> 5);
   if (node >= N) return;
@@ -183,7 +188,14 @@ __global__ __launch_bounds__(256) void k_aggregate(
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   const float* mrow = msg + l * 4;
   int e = e0;
-  for (; e + 2 <= e1; e += 2) {  // 2 rows (4 loads of 16 B) in flight per half-wave
+  int e1r = e1;   // the row range [e, e1r) to add
+  if (PARTS && e1 > e0) {
+    const int m = atom_mol[node];
+    const int me0 = mol_e0[m], base = node + mol_slab0[m];
+    e = base + ((e0 - me0) >> 5);
+    e1r = base + ((e1 - 1 - me0) >> 5) + 1;
+  }
+  for (; e + 2 <= e1r; e += 2) {  // 2 rows (4 loads of 16 B) in flight per half-wave
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(mrow + (size_t)(e + 0) * 256);
     const f32x4 w0 = *reinterpret_cast<const f32x4*>(mrow + (size_t)(e + 0) * 256 + 128);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(mrow + (size_t)(e + 1) * 256);
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(256) void k_aggregate(
     a0 = (a0 + v0) + v1;
     a1 = (a1 + w0) + w1;
   }
-  if (e < e1) {
+  if (e < e1r) {
     a0 += *reinterpret_cast<const f32x4*>(mrow + (size_t)e * 256);
     a1 += *reinterpret_cast<const f32x4*>(mrow + (size_t)e * 256 + 128);
   }
@@ -210,6 +222,52 @@ __global__ __launch_bounds__(256) void k_aggregate(
     const float pu = (first_layer ? 0.f : pos_upd[o]) + d * 0.1f;
     pos_upd[o] = pu;
     pos_cur[o] = pos[o] + pu;
+  }
+}
+
+// Slab tables of the fused edge kernel's REDUCE form (edge_chain.h): the edges of molecule m are cut into slabs of 32
+// counted from the molecule's first edge mol_e0[m] = dst_ptr[mol_ptr[m]]; mol_slab0 = exclusive prefix of the slab
+// counts (mol_slab0[B] = slabs in use).  One workgroup; each thread scans a contiguous run of molecules.
+__global__ __launch_bounds__(1024) void k_slab_scan(const int32_t* __restrict__ mol_ptr, const int32_t* __restrict__ dst_ptr,
+                                                    int B, int32_t* __restrict__ mol_e0, int32_t* __restrict__ mol_slab0) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x, per = (B + 1023) / 1024;
+  const int m0 = t * per, m1 = min(B, m0 + per);
+  int sum = 0;
+  for (int m = m0; m < m1; ++m) sum += (dst_ptr[mol_ptr[m + 1]] - dst_ptr[mol_ptr[m]] + 31) >> 5;
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // inclusive Hillis-Steele scan
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  for (int m = m0; m < m1; ++m) {
+    const int a = dst_ptr[mol_ptr[m]];
+    mol_e0[m] = a;
+    mol_slab0[m] = run;
+    run += (dst_ptr[mol_ptr[m + 1]] - a + 31) >> 5;
+  }
+  if (t == 1023) { mol_e0[B] = dst_ptr[mol_ptr[B]]; mol_slab0[B] = part[1023]; }
+}
+// slab_e0 / slab_cnt [n_cap]: workgroups [0, ceil(B / 4)) fill the slabs of one molecule per wave, the rest clear the
+// entries past the slabs in use.
+__global__ __launch_bounds__(256) void k_slab_fill(const int32_t* __restrict__ mol_e0, const int32_t* __restrict__ mol_slab0,
+                                                   int B, int n_cap, int32_t* __restrict__ slab_e0, int32_t* __restrict__ slab_cnt) {
+  const int nb_mol = (B + 3) >> 2;
+  if ((int)blockIdx.x < nb_mol) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= B) return;
+    const int a = mol_e0[m], b = mol_e0[m + 1], s0 = mol_slab0[m];
+    for (int k = lane; a + 32 * k < b; k += 64) {
+      slab_e0[s0 + k] = a + 32 * k;
+      slab_cnt[s0 + k] = min(32, b - (a + 32 * k));
+    }
+  } else {
+    const int i = (blockIdx.x - nb_mol) * 256 + threadIdx.x;
+    if (i < n_cap && i >= mol_slab0[B]) { slab_e0[i] = 0; slab_cnt[i] = 0; }
   }
 }
 

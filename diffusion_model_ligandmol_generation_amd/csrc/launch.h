@@ -67,6 +67,14 @@ static inline bool use_chain(int64_t rows) {
   const int64_t n = (rows + 127) / 128 * chain_concurrent_calls(), cu = device_cus();
   return n > 0 && 2 * n >= cu;   // at least half of the chip's workgroup slots are used
 }
+// REDUCE form of the fused edge kernel (edge_chain.h).  LIGDIFF_EDGE_REDUCE in the environment: "0" never, "1"
+// whenever the fused edge kernel runs, otherwise for graphs that average at least eight incoming edges per atom (there
+// the [E,256] message tensor is the largest buffer of a layer; on bond-template graphs of two or three edges per atom
+// the aggregation launch is already a few microseconds of cache reads).
+static inline bool edge_reduce_wanted(int64_t n_atoms, int64_t n_edges) {
+  static const int v = [] { const char* e = getenv("LIGDIFF_EDGE_REDUCE"); return e == nullptr || e[0] == '\0' ? -1 : e[0] != '0'; }();
+  return v < 0 ? n_edges >= 8 * n_atoms : v != 0;
+}
 // Column-split GEMM launches of few rows: a 128-row workgroup is eight waves, two to a SIMD, and a wave's tile is a
 // fixed chain of MFMAs, so a launch whose 128-row workgroups cover at most half of the CUs runs as 64-row
 // workgroups (four waves, one to a SIMD, on twice as many CUs) in about half the time (2n <= CUs is the first case

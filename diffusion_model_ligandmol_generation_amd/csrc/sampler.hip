@@ -246,9 +246,6 @@ extern "C" int ligdiff_ddim_step(const ligdiff_step_args* a, int32_t t_cur, int3
 // property embedding, [B, 2B) without): twice the rows per launch fills the GPU where B molecules
 // alone leave most GEMMs at one workgroup per CU.  Molecules never interact, so the result equals two
 // separate passes bit for bit.  LIGDIFF_CFG_TWO_PASS=1 keeps the two-pass form (A/B switch used by the tests).
-static bool cfg_one_pass() {   // read per call: the tests flip it within one process
-  return getenv("LIGDIFF_CFG_TWO_PASS") == nullptr && fwd_column_split_gemms();
-}
 struct SampleLayout {
   size_t fwd, eps_x, eps_pos, eps_xu, eps_pu, t_index, tvals, tf, t1, stemb, tab_temb, tab_mod[3];
   // doubled batch of the one-pass guided form: state copies and the int32 arrays of its ligdiff_graph
@@ -547,6 +544,32 @@ static int sample_loop(const float* const* weights, const ligdiff_graph* graph, 
   if (exec4) (void)hipGraphExecDestroy(exec4);
   if (exec1) (void)hipGraphExecDestroy(exec1);
   return rc;
+}
+
+extern "C" int ligdiff_ddpm_sample_opt(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                                       const float* properties, float guidance_scale, float temperature,
+                                       const float* betas, const float* alphas, const float* alphas_cumprod,
+                                       int32_t n_steps, uint64_t seed, int64_t atom_offset, int use_graph,
+                                       void* workspace, size_t workspace_bytes, void* stream, const ligdiff_options* options) {
+  if (check_options(options)) return LIGDIFF_ERR_ARG;
+  CallOptions scope(options);
+  return ligdiff_ddpm_sample(weights, graph, x, pos, properties, guidance_scale, temperature, betas, alphas, alphas_cumprod,
+                             n_steps, seed, atom_offset, use_graph, workspace, workspace_bytes, stream);
+}
+extern "C" size_t ligdiff_ddpm_sample_workspace_bytes_opt(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided,
+                                                          int32_t n_steps, const ligdiff_options* options) {
+  if (check_options(options)) return 0;
+  CallOptions scope(options);
+  return ligdiff_ddpm_sample_workspace_bytes(n_atoms, n_edges, n_mols, guided, n_steps);
+}
+extern "C" int ligdiff_ddim_sample_opt(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                                       const float* properties, float guidance_scale, const float* alphas_cumprod,
+                                       const int32_t* timesteps, int32_t n_steps, int32_t* reject, int use_graph,
+                                       void* workspace, size_t workspace_bytes, void* stream, const ligdiff_options* options) {
+  if (check_options(options)) return LIGDIFF_ERR_ARG;
+  CallOptions scope(options);
+  return ligdiff_ddim_sample(weights, graph, x, pos, properties, guidance_scale, alphas_cumprod, timesteps, n_steps, reject,
+                             use_graph, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,

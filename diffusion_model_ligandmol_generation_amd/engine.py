@@ -6,11 +6,12 @@ entry points on the current HIP stream.
 """
 import ctypes as C
 import math
+import threading
 
 import torch
 
 from . import _lib
-from ._lib import Graph, check
+from ._lib import Graph, Options, check
 
 
 def _ptr(t):
@@ -19,6 +20,11 @@ def _ptr(t):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _opt(options):
+    """ctypes argument for an optional ligdiff_options struct."""
+    return C.byref(options) if options is not None else None
 
 
 def _require_cuda(t, name):
@@ -110,7 +116,7 @@ class ScoreNetworkEngine:
             self.table[i] = t.data_ptr()
             self._sig.append(t.data_ptr())
         self._params = params
-        self._ws = None
+        self._tls = threading.local()   # workspace cache and side stream of the calling thread
         self.max_atoms = model.max_atoms
 
     def stale(self, model):
@@ -126,9 +132,29 @@ class ScoreNetworkEngine:
         Process-wide (include/ligdiff.h: ligdiff_set_split_gemm)."""
         return bool(self.lib.ligdiff_set_split_gemm(1 if enabled else 0))
 
-    def ddpm_workspace_bytes(self, graph, guided, n_steps):
-        return int(self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols,
-                                                                1 if guided else 0, int(n_steps)))
+    def ddpm_workspace_bytes(self, graph, guided, n_steps, options=None):
+        return int(self.lib.ligdiff_ddpm_sample_workspace_bytes_opt(graph.n_atoms, graph.n_edges, graph.n_mols,
+                                                                    1 if guided else 0, int(n_steps), _opt(options)))
+
+    @staticmethod
+    def options(**fields):
+        """A ligdiff_options struct with the given fields set (gemm_mode, chain_mode, concurrent_calls, edge_chain,
+        node_chain, mol_wave, edge_reduce, cfg_two_pass); everything else stays "not set"."""
+        return Options(**fields)
+
+    def plan(self, n_atoms, n_edges, n_mols, max_mol_atoms, options=None):
+        """ligdiff_plan: the kernel forms the library would pick for ONE call over a request of these sizes,
+        as an Options struct to pass to every call that processes a part of the request (halves on two
+        streams, shards): the parts then produce the bits of the whole, whatever their own sizes.
+        Fields that ``options`` already sets are kept."""
+        out = Options()
+        with torch.cuda.device(self.device):
+            check(self.lib.ligdiff_plan(int(n_atoms), int(n_edges), int(n_mols), int(max_mol_atoms), _opt(options),
+                                        C.byref(out)), "ligdiff_plan")
+        return out
+
+    def plan_graph(self, graph, options=None):
+        return self.plan(graph.n_atoms, graph.n_edges, graph.n_mols, graph.max_mol_atoms, options)
 
     def set_concurrent_calls(self, k):
         """Hint for k concurrent library calls on one GPU (include/ligdiff.h: ligdiff_set_concurrent_calls);
@@ -147,12 +173,15 @@ class ScoreNetworkEngine:
         return prev
 
     def workspace(self, nbytes):
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws
+        """Cached workspace tensor of the calling host thread (library calls made from different threads run
+        concurrently on their own streams and must not share one)."""
+        ws = getattr(self._tls, "ws", None)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._tls.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return ws
 
     def forward(self, graph, x, pos, t, properties=None, null_cond=False, want_props=True, save=False,
-                workspace=None, t_index=None, keep_state=False, dropout=None):
+                workspace=None, t_index=None, keep_state=False, dropout=None, options=None):
         """ligdiff_forward on the current stream.  t: [B] float tensor (or [1], applied to
         every molecule); alternatively t_index, a device int32 scalar holding the step.
         Returns atom_pred, pos_pred, prop_pred (None if not wanted)."""
@@ -192,17 +221,17 @@ class ScoreNetworkEngine:
             flags |= _lib.FWD_SKIP_PROP_HEAD
         if save:
             flags |= _lib.FWD_SAVE_FOR_BACKWARD
-        nbytes = self.lib.ligdiff_forward_workspace_bytes(N, graph.n_edges, B, flags)
+        nbytes = self.lib.ligdiff_forward_workspace_bytes_opt(N, graph.n_edges, B, flags, _opt(options))
         ws = workspace if workspace is not None else self.workspace(nbytes)
         atom_pred = torch.empty(N, 119, dtype=torch.float32, device=self.device)
         pos_pred = torch.empty(N, 3, dtype=torch.float32, device=self.device)
         prop_pred = torch.empty(B, 15, dtype=torch.float32, device=self.device) if want_props else None
         with torch.cuda.device(self.device):
-            rc = self.lib.ligdiff_forward_train(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(t), _ptr(t_index),
-                                                _ptr(properties) if (properties is not None and not null_cond) else None,
-                                                flags, _ptr(atom_pred), _ptr(pos_pred), _ptr(prop_pred), _ptr(ws),
-                                                ws.numel(), _stream(),
-                                                C.byref(dropout) if dropout is not None else None)
+            rc = self.lib.ligdiff_forward_opt(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(t), _ptr(t_index),
+                                              _ptr(properties) if (properties is not None and not null_cond) else None,
+                                              flags, _ptr(atom_pred), _ptr(pos_pred), _ptr(prop_pred), _ptr(ws),
+                                              ws.numel(), _stream(),
+                                              C.byref(dropout) if dropout is not None else None, _opt(options))
         check(rc, "ligdiff_forward")
         self.last_forward = (ws, flags) if keep_state else None   # for consistency() right after this call
         return atom_pred, pos_pred, prop_pred
@@ -214,19 +243,19 @@ class ScoreNetworkEngine:
             raise RuntimeError(f"a molecule has {graph.max_mol_atoms} atoms but the model was built with "
                                f"max_atoms={self.max_atoms} (model1.py:728)")
 
-    def time_launch(self, label, graph, x, pos, t_index, reps=5):
+    def time_launch(self, label, graph, x, pos, t_index, reps=5, options=None):
         """Mean duration in ms (HIP events on the launch stream) of one labelled launch of
         the forward pass in situ; measurement hook used by bench.py."""
         flags = _lib.FWD_T_BROADCAST | _lib.FWD_SKIP_PROP_HEAD
-        nbytes = self.lib.ligdiff_forward_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, flags)
+        nbytes = self.lib.ligdiff_forward_workspace_bytes_opt(graph.n_atoms, graph.n_edges, graph.n_mols, flags, _opt(options))
         ws = self.workspace(nbytes)
         a = torch.empty(graph.n_atoms, 119, dtype=torch.float32, device=self.device)
         p = torch.empty(graph.n_atoms, 3, dtype=torch.float32, device=self.device)
         ms = C.c_float(0.0)
         with torch.cuda.device(self.device):
-            rc = self.lib.ligdiff_forward_timed(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), None, _ptr(t_index),
-                                                None, flags, _ptr(a), _ptr(p), None, _ptr(ws), ws.numel(), _stream(),
-                                                label.encode(), int(reps), C.byref(ms))
+            rc = self.lib.ligdiff_forward_timed_opt(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), None, _ptr(t_index),
+                                                    None, flags, _ptr(a), _ptr(p), None, _ptr(ws), ws.numel(), _stream(),
+                                                    label.encode(), int(reps), C.byref(ms), _opt(options))
         check(rc, f"ligdiff_forward_timed({label})")
         return float(ms.value)
 
@@ -333,7 +362,7 @@ class ScoreNetworkEngine:
                                             int(step), int(atom_offset), _stream()), "ligdiff_pos_step")
 
     def ddpm_sample(self, model, graph, x, pos, properties=None, guidance_scale=1.0, temperature=1.0,
-                    n_steps=None, seed=0, atom_offset=0, use_graph=True, workspace=None, stream=None):
+                    n_steps=None, seed=0, atom_offset=0, use_graph=True, workspace=None, stream=None, options=None):
         """Whole reverse loop in the library (hipGraph replay); x / pos updated in place.
         workspace / stream: a caller that runs several of these calls concurrently (one host thread each)
         gives every call its own workspace tensor and its own non-default stream; the call then returns
@@ -341,8 +370,8 @@ class ScoreNetworkEngine:
         n_steps = model.timesteps if n_steps is None else n_steps
         self._check_sizes(graph)
         guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
-        nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
-                                                              int(n_steps))
+        nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes_opt(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
+                                                                  int(n_steps), _opt(options))
         if workspace is not None and workspace.numel() < nbytes:
             raise ValueError("workspace too small")
         ws = self.workspace(nbytes) if workspace is None else workspace
@@ -350,11 +379,11 @@ class ScoreNetworkEngine:
             if properties is not None:
                 properties = properties.contiguous().float()
             with torch.cuda.device(self.device), torch.cuda.stream(stream):
-                rc = self.lib.ligdiff_ddpm_sample(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
-                                                  float(guidance_scale), float(temperature), _ptr(model.betas),
-                                                  _ptr(model.alphas), _ptr(model.alphas_cumprod), int(n_steps),
-                                                  int(seed), int(atom_offset), 1 if use_graph else 0, _ptr(ws),
-                                                  ws.numel(), C.c_void_p(stream.cuda_stream))
+                rc = self.lib.ligdiff_ddpm_sample_opt(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
+                                                      float(guidance_scale), float(temperature), _ptr(model.betas),
+                                                      _ptr(model.alphas), _ptr(model.alphas_cumprod), int(n_steps),
+                                                      int(seed), int(atom_offset), 1 if use_graph else 0, _ptr(ws),
+                                                      ws.numel(), C.c_void_p(stream.cuda_stream), _opt(options))
             check(rc, "ligdiff_ddpm_sample")
             return
         if properties is not None:
@@ -366,29 +395,29 @@ class ScoreNetworkEngine:
             # stream capture is not possible on the legacy default stream: hop to a side stream
             run_on = cur
             if use_graph and cur.cuda_stream == 0:
-                if getattr(self, "_side", None) is None:
-                    self._side = torch.cuda.Stream(device=self.device)
-                run_on = self._side
+                if getattr(self._tls, "side", None) is None:
+                    self._tls.side = torch.cuda.Stream(device=self.device)
+                run_on = self._tls.side
                 run_on.wait_stream(cur)
             with torch.cuda.stream(run_on):
-                rc = self.lib.ligdiff_ddpm_sample(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
-                                                  float(guidance_scale), float(temperature), _ptr(model.betas),
-                                                  _ptr(model.alphas), _ptr(model.alphas_cumprod), int(n_steps),
-                                                  int(seed), int(atom_offset), 1 if use_graph else 0, _ptr(ws),
-                                                  ws.numel(), _stream())
+                rc = self.lib.ligdiff_ddpm_sample_opt(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
+                                                      float(guidance_scale), float(temperature), _ptr(model.betas),
+                                                      _ptr(model.alphas), _ptr(model.alphas_cumprod), int(n_steps),
+                                                      int(seed), int(atom_offset), 1 if use_graph else 0, _ptr(ws),
+                                                      ws.numel(), _stream(), _opt(options))
             if run_on is not cur:
                 cur.wait_stream(run_on)
         check(rc, "ligdiff_ddpm_sample")
 
     def ddim_sample(self, model, graph, x, pos, timesteps, reject, properties=None, guidance_scale=1.0,
-                    use_graph=True):
+                    use_graph=True, options=None):
         """Whole DDIM loop in the library (ligdiff_ddim_sample); x / pos updated in place, ``reject``
         [B] int32 receives the per-step prediction gate.  timesteps: list of ints."""
         n_steps = len(timesteps)
         self._check_sizes(graph)
         guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
-        nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
-                                                              n_steps)
+        nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes_opt(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
+                                                                  n_steps, _opt(options))
         ws = self.workspace(nbytes)
         ts = torch.tensor([int(t) for t in timesteps], dtype=torch.int32, device=self.device)
         if properties is not None:
@@ -399,14 +428,15 @@ class ScoreNetworkEngine:
             cur = torch.cuda.current_stream()
             run_on = cur
             if use_graph and cur.cuda_stream == 0:     # the legacy default stream cannot be captured
-                if getattr(self, "_side", None) is None:
-                    self._side = torch.cuda.Stream(device=self.device)
-                run_on = self._side
+                if getattr(self._tls, "side", None) is None:
+                    self._tls.side = torch.cuda.Stream(device=self.device)
+                run_on = self._tls.side
                 run_on.wait_stream(cur)
             with torch.cuda.stream(run_on):
-                rc = self.lib.ligdiff_ddim_sample(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
-                                                  float(guidance_scale), _ptr(model.alphas_cumprod), _ptr(ts), n_steps,
-                                                  _ptr(reject), 1 if use_graph else 0, _ptr(ws), ws.numel(), _stream())
+                rc = self.lib.ligdiff_ddim_sample_opt(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
+                                                      float(guidance_scale), _ptr(model.alphas_cumprod), _ptr(ts), n_steps,
+                                                      _ptr(reject), 1 if use_graph else 0, _ptr(ws), ws.numel(), _stream(),
+                                                      _opt(options))
             if run_on is not cur:
                 cur.wait_stream(run_on)
         check(rc, "ligdiff_ddim_sample")

@@ -45,6 +45,11 @@ class ResearchValidatedGenerator:
         # neutral from 700 to 900, and a loss below 550, where a half no longer fills half of the chip).  None switches it off.
         self.concurrent_atoms = 17000
         self._half_streams = []
+        # Per-call library options (an engine Options struct, or None for the library's defaults).  Whatever it
+        # leaves open is resolved ONCE per packed batch from the whole batch's sizes (engine.plan_graph) and the
+        # resolved struct goes to every library call of that batch, so the two halves take the kernel forms the
+        # single call would take and the process-wide switches of the library are never touched.
+        self.options = None
         # Philox seed of the next call.  None: every call draws a fresh 62-bit seed from torch's global
         # CPU generator, so consecutive calls differ (as the reference's torch.randn draws do,
         # generation.py:291, :405, :469) and torch.manual_seed makes a run repeatable.  An int: used
@@ -89,12 +94,14 @@ class ResearchValidatedGenerator:
         return 2 * n + 4
 
     def sample_many(self, sizes, target_properties=None, guidance_scale=2.0, temperature=1.0, use_ddim=False,
-                    num_steps=100, seed=None, connectivity="template", atom_offset=0):
+                    num_steps=100, seed=None, connectivity="template", atom_offset=0, options=None):
         """Samples every size in ``sizes``; returns ([(x_np, pos_np)], [accepted bool]).
         connectivity: "template" (the generator's bond template, generation.py:562-668) or "full"
         (every ordered atom pair of a molecule).  Without ``seed`` every call uses a new one.
         atom_offset: global index of the first atom (a rank sampling one shard of a larger request
-        passes the atoms that precede its shard, which keeps the draws independent of the sharding)."""
+        passes the atoms that precede its shard, which keeps the draws independent of the sharding).
+        options: a resolved plan (engine.plan on the sizes of the WHOLE request) when this call samples one
+        shard of it; without it every packed batch plans for itself."""
         seed = self._next_seed() if seed is None else seed
         results, flags = [], []
         i = 0
@@ -111,7 +118,7 @@ class ResearchValidatedGenerator:
                 chunk = sizes[i:j]
                 x, pos, graph, rejected = self.sample_batch(chunk, target_properties, guidance_scale, temperature,
                                                             use_ddim, num_steps, seed=seed, atom_offset=atom_offset,
-                                                            connectivity=connectivity)
+                                                            connectivity=connectivity, options=options)
                 accept = self.model.engine().validity_gate(x, pos, graph.mol_ptr, graph.n_mols)
                 accept = (accept.bool() & ~rejected.bool()).cpu().numpy()
                 xh, ph = x.cpu().numpy(), pos.cpu().numpy()       # generation.py:246
@@ -123,7 +130,8 @@ class ResearchValidatedGenerator:
                 i = j
         return results, flags
 
-    def _ddpm_two_halves(self, sizes, connectivity, x, pos, props, guidance_scale, temperature, T, seed, atom_offset):
+    def _ddpm_two_halves(self, sizes, connectivity, x, pos, props, guidance_scale, temperature, T, seed, atom_offset,
+                         options):
         """The reverse loop of one batch as two concurrent library calls on contiguous halves of the molecules
         (balanced by atoms, or by atom pairs for fully connected graphs); x / pos updated in place."""
         import threading
@@ -136,7 +144,7 @@ class ResearchValidatedGenerator:
             part = sizes[lo:hi]
             a0, a1 = sum(int(n) for n in sizes[:lo]), sum(int(n) for n in sizes[:hi])
             g = full_graph(part, dev)[0] if connectivity == "full" else template_graph(part, dev)[0]
-            ws = torch.empty(eng.ddpm_workspace_bytes(g, guided, T), dtype=torch.uint8, device=dev)
+            ws = torch.empty(eng.ddpm_workspace_bytes(g, guided, T, options), dtype=torch.uint8, device=dev)
             # the same two side streams for every call: a stream keeps the hardware queue it was given at creation,
             # and with a fresh pair per call some pairs were seen to share a queue (the halves then run one after
             # the other: 4.2 s instead of 2.4 s for a pass of 1024 ligands)
@@ -150,18 +158,15 @@ class ResearchValidatedGenerator:
         def run(job):
             g, xs, ps, pr, off, ws, st = job
             try:
-                eng.ddpm_sample(model, g, xs, ps, pr, guidance_scale, temperature, T, seed, off, True, workspace=ws, stream=st)
+                eng.ddpm_sample(model, g, xs, ps, pr, guidance_scale, temperature, T, seed, off, True, workspace=ws, stream=st,
+                                options=options)
             except Exception as e:   # noqa: BLE001  (re-raised on the calling thread)
                 errors.append(e)
-        prev = eng.set_concurrent_calls(len(jobs))
-        try:
-            threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-        finally:
-            eng.set_concurrent_calls(prev)
+        threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
         for job in jobs:
             cur.wait_stream(job[6])
         if errors:
@@ -169,7 +174,7 @@ class ResearchValidatedGenerator:
 
     def sample_batch(self, sizes, target_properties=None, guidance_scale=2.0, temperature=1.0, use_ddim=False,
                      num_steps=100, seed=None, atom_offset=0, noise=None, use_graph=True, trace=None,
-                     connectivity="template"):
+                     connectivity="template", options=None):
         """One packed batch through the reverse loop.  Returns (x, pos, graph, rejected[B]).
 
         connectivity: "template" (generation.py:409-416, the reference's only choice), "full" (every
@@ -181,6 +186,9 @@ class ResearchValidatedGenerator:
         {"x0", "pos0", "x", "pos"}; when given, every Gaussian draw is taken from it (parity
         runs) and the loop is driven step by step from the host.
         trace: optional callable ``trace(t, x, pos)`` seeing the state that enters step t.
+        options: per-call library options for this batch (an engine Options struct, e.g. the plan of a
+        larger request this batch is a shard of); None takes ``self.options``.  Kernel forms they leave
+        open are fixed here, once, on this batch's sizes.
         """
         model, eng, dev = self.model, self.model.engine(), self.device
         seed = self._next_seed() if seed is None else seed
@@ -212,18 +220,25 @@ class ResearchValidatedGenerator:
             x = (noise("x0", T, (N, 119)) * temperature).contiguous()
             pos = (noise("pos0", T, (N, 3)) * temperature).contiguous()
         rejected = torch.zeros(B, dtype=torch.int32, device=dev)
+        halves = (not use_ddim and noise is None and trace is None and use_graph and self.concurrent_atoms is not None
+                  and N >= self.concurrent_atoms and B >= 8 and connectivity in ("template", "full"))
+        # kernel forms of this batch, fixed on the whole batch's sizes whichever way it is then cut
+        opts = eng.plan_graph(graph, options if options is not None else self.options)
+        if halves:   # the hint only steers choices between bit-identical GEMM tile forms once the plan is fixed
+            opts = opts.copy(concurrent_calls=2)
         if not use_ddim and noise is None and trace is None:
-            if (use_graph and self.concurrent_atoms is not None and N >= self.concurrent_atoms and B >= 8
-                    and connectivity in ("template", "full")):
-                self._ddpm_two_halves(sizes, connectivity, x, pos, props, guidance_scale, temperature, T, seed, atom_offset)
+            if halves:
+                self._ddpm_two_halves(sizes, connectivity, x, pos, props, guidance_scale, temperature, T, seed, atom_offset,
+                                      opts)
             else:
-                eng.ddpm_sample(model, graph, x, pos, props, guidance_scale, temperature, T, seed, atom_offset, use_graph)
+                eng.ddpm_sample(model, graph, x, pos, props, guidance_scale, temperature, T, seed, atom_offset, use_graph,
+                                options=opts)
             return x, pos, graph, rejected
         t_index = torch.zeros(1, dtype=torch.int32, device=dev)
         if use_ddim:
             steps = torch.linspace(T - 1, 0, num_steps, dtype=torch.long).tolist()  # generation.py:305
             if noise is None and trace is None:
-                eng.ddim_sample(model, graph, x, pos, steps, rejected, props, guidance_scale, use_graph)
+                eng.ddim_sample(model, graph, x, pos, steps, rejected, props, guidance_scale, use_graph, options=opts)
                 return x, pos, graph, rejected
         else:
             steps = list(range(T - 1, -1, -1))                                    # generation.py:422
@@ -231,10 +246,10 @@ class ResearchValidatedGenerator:
             if trace is not None:
                 trace(t, x, pos)
             t_index.fill_(t)
-            ex, ep, _ = eng.forward(graph, x, pos, None, props, want_props=False, t_index=t_index)
+            ex, ep, _ = eng.forward(graph, x, pos, None, props, want_props=False, t_index=t_index, options=opts)
             exu = epu = None
             if guided:
-                exu, epu, _ = eng.forward(graph, x, pos, None, None, want_props=False, t_index=t_index)
+                exu, epu, _ = eng.forward(graph, x, pos, None, None, want_props=False, t_index=t_index, options=opts)
             nx = npos = None
             if not use_ddim and noise is not None and t > 1:
                 nx, npos = noise("x", t, (N, 119)).contiguous(), noise("pos", t, (N, 3)).contiguous()

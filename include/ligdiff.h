@@ -7,10 +7,13 @@
  * hipMalloc or hipFree.  Every entry point takes the hipStream_t (as void*) it enqueues on and
  * returns an int status, 0 = ok.
  *
- * Process-wide state, all of it listed here:
+ * Per-call choices (GEMM mode, fused or separate kernels, concurrency hint, guidance in one or two passes)
+ * travel in a ligdiff_options struct through the *_opt entry points; a call that is given options reads
+ * nothing below for the fields it sets.  The process-wide setters are the DEFAULTS of calls without options
+ * and are kept for existing callers (deprecated):
  *  - the GEMM mode (ligdiff_set_split_gemm, or LIGDIFF_GEMM_SPLIT in the environment): it changes what
  *    the *_workspace_bytes functions return, so size workspaces after choosing it and do not switch
- *    while another thread is inside a call;
+ *    while another thread is inside a call that relies on the default;
  *  - the concurrency hint (ligdiff_set_concurrent_calls) and the chain-kernel choice (ligdiff_set_chain_mode);
  *  - LIGDIFF_CFG_TWO_PASS (environment, read at every sampling call and workspace query);
  *  - A/B switches read once from the environment (LIGDIFF_GEMM_V1, LIGDIFF_GEMM_NOCS, LIGDIFF_CHAIN / LIGDIFF_NO_CHAIN, LIGDIFF_CHAIN_MOL,
@@ -129,6 +132,39 @@ int ligdiff_pack_csr_static(const int64_t* edge_index, int64_t n_edges, const in
                             int32_t* src_ptr, int32_t* src_slot, int32_t* status_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * Per-call options.  The inference path has two forms of several layers - fused "chain" kernels and
+ * separate launches - that compute the same layers (model1.py:60-114, :255-302) and agree to fp32
+ * rounding but not bit for bit, and by default picks per launch by how well it fills the chip.  A
+ * caller that cuts ONE request into several calls (halves on two streams, shards on several GPUs) and
+ * wants the pieces to produce the bits of the whole plans once with ligdiff_plan on the whole
+ * request's sizes and passes the resolved struct to every piece.
+ * Every field: -1 (or 0 for concurrent_calls) = not set, the process default applies.
+ * No counterpart in the reference (one device, one kernel per ATen op).
+ * ------------------------------------------------------------------------------- */
+typedef struct ligdiff_options {
+  int32_t gemm_mode;         /* 0 fp32 matrix pipe, 1 split-operand bf16 pipe (see ligdiff_set_split_gemm)   */
+  int32_t chain_mode;        /* 0 never fused, 1 by fill, 2 always (see ligdiff_set_chain_mode); the four    */
+                             /* fields below override it form by form                                        */
+  int32_t concurrent_calls;  /* 1..16: calls sharing the GPU (see ligdiff_set_concurrent_calls); affects     */
+                             /* only choices between bit-identical forms once the fields below are set       */
+  int32_t edge_chain;        /* 0 / 1: fused edge path of the E(3) layers                                    */
+  int32_t node_chain;        /* 0 / 1: fused node update and attention-layer kernels                         */
+  int32_t mol_wave;          /* 0 / 1: molecule-per-wave attention layers (needs molecules of <= 32 atoms)   */
+  int32_t edge_reduce;       /* 0 / 1: the fused edge path sums messages per destination itself              */
+  int32_t cfg_two_pass;      /* 0 guided sampling as one doubled forward, 1 as two forwards                  */
+} ligdiff_options;
+
+/* Sets every field of *o to "not set". */
+void ligdiff_options_init(ligdiff_options* o);
+
+/* Resolves the kernel-form fields (edge_chain, node_chain, mol_wave, edge_reduce) that `in` (may be NULL)
+ * leaves unset into 0 / 1 for a request of these sizes on the current device, as the library would choose
+ * for ONE call over the whole request; the other fields are copied.  Pass *out to every call that
+ * processes a part of the request: the parts then take the same forms, whatever their own sizes. */
+int ligdiff_plan(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int32_t max_mol_atoms,
+                 const ligdiff_options* in, ligdiff_options* out);
+
+/* ---------------------------------------------------------------------------------
  * Score-network forward.  Replaces ResearchAccurateDiffusionModel.forward in eval mode
  * (model1.py:699-755): embeddings, 3 E(3) message-passing layers (model1.py:86-114),
  * 3 adaLN attention layers over each molecule's own atoms (model1.py:279-302; equal to
@@ -192,6 +228,15 @@ int ligdiff_forward_train(const float* const* weights, const ligdiff_graph* grap
                           float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
                           const ligdiff_dropout* dropout);
 
+/* ligdiff_forward_train / ligdiff_forward_workspace_bytes under per-call options (NULL = the defaults). */
+size_t ligdiff_forward_workspace_bytes_opt(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int flags,
+                                           const ligdiff_options* options);
+int ligdiff_forward_opt(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                        const float* pos, const float* t, const int32_t* t_index_dev,
+                        const float* properties, int flags, float* atom_pred, float* pos_pred,
+                        float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
+                        const ligdiff_dropout* dropout, const ligdiff_options* options);
+
 /* Writes the mask scale (0 or 1 / (1 - p)) of every element of one dropout site for atoms
  * [0, n_atoms) of a call made with `dropout`: kind LIGDIFF_DROP_FFN_HIDDEN -> out [n_atoms, 1024],
  * LIGDIFF_DROP_FFN_OUT -> out [n_atoms, 256], LIGDIFF_DROP_ATTENTION -> out [n_atoms, 8, 128] indexed
@@ -222,6 +267,15 @@ int ligdiff_backward_train(const float* const* weights, float* const* grads, con
                            const float* d_atom, const float* d_pos, const float* d_prop,
                            const void* fwd_workspace, void* workspace, size_t workspace_bytes, void* stream,
                            const ligdiff_dropout* dropout);
+/* The same under per-call options (only gemm_mode matters to the backward pass; the forward pass whose
+ * workspace it reads must have run under the same gemm_mode). */
+size_t ligdiff_backward_workspace_bytes_opt(int64_t n_atoms, int64_t n_edges, int32_t n_mols,
+                                            const ligdiff_options* options);
+int ligdiff_backward_opt(const float* const* weights, float* const* grads, const ligdiff_graph* graph,
+                         const float* x, const float* pos, const float* properties, int flags,
+                         const float* d_atom, const float* d_pos, const float* d_prop,
+                         const void* fwd_workspace, void* workspace, size_t workspace_bytes, void* stream,
+                         const ligdiff_dropout* dropout, const ligdiff_options* options);
 
 /* Measurement hook (no counterpart in the reference): runs `reps` backward passes with the arguments
  * of ligdiff_backward (gradients keep accumulating into `grads`: pass throw-away buffers) and
@@ -344,6 +398,12 @@ int ligdiff_forward_timed(const float* const* weights, const ligdiff_graph* grap
                           const float* properties, int flags, float* atom_pred, float* pos_pred,
                           float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
                           const char* label, int32_t reps, float* mean_ms_host);
+/* The same under per-call options. */
+int ligdiff_forward_timed_opt(const float* const* weights, const ligdiff_graph* graph, const float* x,
+                              const float* pos, const float* t, const int32_t* t_index_dev,
+                              const float* properties, int flags, float* atom_pred, float* pos_pred,
+                              float* prop_pred, void* workspace, size_t workspace_bytes, void* stream,
+                              const char* label, int32_t reps, float* mean_ms_host, const ligdiff_options* options);
 
 /* ---------------------------------------------------------------------------------
  * Fused reverse-diffusion updates.  Replace the per-step tensor arithmetic of
@@ -409,6 +469,15 @@ int ligdiff_ddpm_sample(const float* const* weights, const ligdiff_graph* graph,
 size_t ligdiff_ddpm_sample_workspace_bytes(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided,
                                            int32_t n_steps);
 
+/* ligdiff_ddpm_sample / its workspace query under per-call options (NULL = the defaults). */
+int ligdiff_ddpm_sample_opt(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                            const float* properties, float guidance_scale, float temperature,
+                            const float* betas, const float* alphas, const float* alphas_cumprod,
+                            int32_t n_steps, uint64_t seed, int64_t atom_offset, int use_graph,
+                            void* workspace, size_t workspace_bytes, void* stream, const ligdiff_options* options);
+size_t ligdiff_ddpm_sample_workspace_bytes_opt(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int guided,
+                                               int32_t n_steps, const ligdiff_options* options);
+
 /* Whole DDIM loop of generation.py:279-381 (the generator's default mode), same structure as
  * ligdiff_ddpm_sample: timesteps [n_steps] (device int32, generation.py:305: linspace(T-1, 0,
  * n_steps) truncated) are walked front to back; the update of position i uses
@@ -421,6 +490,12 @@ int ligdiff_ddim_sample(const float* const* weights, const ligdiff_graph* graph,
                         const float* properties, float guidance_scale, const float* alphas_cumprod,
                         const int32_t* timesteps, int32_t n_steps, int32_t* reject, int use_graph,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ligdiff_ddim_sample under per-call options (workspace: ligdiff_ddpm_sample_workspace_bytes_opt). */
+int ligdiff_ddim_sample_opt(const float* const* weights, const ligdiff_graph* graph, float* x, float* pos,
+                            const float* properties, float guidance_scale, const float* alphas_cumprod,
+                            const int32_t* timesteps, int32_t n_steps, int32_t* reject, int use_graph,
+                            void* workspace, size_t workspace_bytes, void* stream, const ligdiff_options* options);
 
 /* Fills out[n] with the N(0,1) draws the in-kernel Philox stream yields for
  * (seed, step, global element index offset..offset+n): lets a host reproduce a run. */

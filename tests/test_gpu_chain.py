@@ -89,3 +89,120 @@ def test_half_tile_gemms_are_bitwise_the_full_tile_ones(tmp_path):
     for k in half.files:
         assert np.isfinite(half[k]).all(), k
         assert np.array_equal(half[k], full[k]), k
+
+
+def _model_gen(max_atoms=100, timesteps=1000):
+    import torch
+    from diffusion_model_ligandmol_generation_amd import ResearchAccurateDiffusionModel
+    from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
+    torch.manual_seed(0)
+    model = ResearchAccurateDiffusionModel(max_atoms=max_atoms, timesteps=timesteps).cuda().eval()
+    return model, ResearchValidatedGenerator(model)
+
+
+def test_edge_reduce_form_matches_message_rows():
+    """Fused edge kernel with the per-destination sums taken inside it (REDUCE form, csrc/edge_chain.h: the [E,256]
+    message tensor never reaches memory) against the same kernel storing the messages for k_aggregate: fully connected
+    65 / 100 / 128-atom ligands (two to five 32-edge slabs per destination, slab boundaries inside destinations) and
+    template ligands (several destinations per slab), one forward and a short sampling call each.  Different summation order (per-slab partial sums), so a tolerance, not bits."""
+    import torch
+    from diffusion_model_ligandmol_generation_amd.engine import full_graph, template_graph
+    model, gen = _model_gen(128, timesteps=8)     # the DDPM loop runs model.timesteps reverse steps
+    eng = model.engine()
+    dev = torch.device("cuda")
+    t = torch.tensor([5], dtype=torch.int32, device=dev)
+    for sizes, fc in (([65, 100, 128, 77, 2, 3], True), ([29] * 9 + [5, 16, 128, 64], False)):
+        g = full_graph(sizes, dev)[0] if fc else template_graph(sizes, dev)[0]
+        gg = torch.Generator().manual_seed(5)
+        x = torch.randn(g.n_atoms, 119, generator=gg).to(dev)
+        pos = (torch.randn(g.n_atoms, 3, generator=gg) * 1.5).to(dev)
+        outs = []
+        for red in (0, 1):
+            o = eng.options(chain_mode=2, edge_reduce=red)
+            with torch.no_grad():
+                a, p, _ = eng.forward(g, x, pos, None, None, want_props=False, t_index=t, options=o)
+            outs.append((a.clone(), p.clone()))
+        for u, v in zip(outs[0], outs[1]):
+            assert torch.isfinite(u).all() and torch.isfinite(v).all()
+            assert not torch.equal(u, v)           # the REDUCE form really ran
+            scale = max(1.0, float(u.abs().max()))
+            assert float((u - v).abs().max()) <= 2e-5 * scale, (fc, float((u - v).abs().max()), scale)
+        res = []
+        for red in (0, 1):
+            gen.options = eng.options(chain_mode=2, edge_reduce=red)
+            xs, ps, _, _ = gen.sample_batch(sizes[:4], None, 1.0, 1.0, seed=11, connectivity="full" if fc else "template")
+            res.append((xs.clone(), ps.clone()))
+        gen.options = None
+        for u, v in zip(res[0], res[1]):
+            assert torch.isfinite(u).all() and torch.isfinite(v).all()
+            assert float((u - v).abs().max()) <= 2e-4 * max(1.0, float(u.abs().max()))
+
+
+def test_plan_fixes_kernel_forms_for_halves_and_shards():
+    """By-fill mode (no LIGDIFF_CHAIN override) at a size just above the fill threshold of the fused kernels, where a
+    half or a shard on its own would fall below it: the generator plans ONCE on the whole batch (ligdiff_plan) and
+    hands the plan to every part, so two concurrent halves, two separately sampled shards and the single call agree
+    bit for bit."""
+    import torch
+    model, gen = _model_gen(timesteps=6)
+    eng = model.engine()
+    sizes = [29] * 570                      # 16 530 atoms = 130 row blocks of 128: above half of 256 CUs; a half is 65
+    by_fill = eng.options(chain_mode=1)
+    whole = eng.plan(sum(sizes), 62 * len(sizes), len(sizes), 29, by_fill)
+    part = eng.plan(sum(sizes) // 2, 31 * len(sizes), len(sizes) // 2, 29, by_fill)
+    assert whole.node_chain == 1 and whole.edge_chain == 1 and part.node_chain == 0   # the threshold is between them
+    gen.options = by_fill
+    gen.concurrent_atoms = None
+    x1, p1, _, _ = gen.sample_batch(sizes, None, 1.0, 1.0, seed=5)
+    gen.concurrent_atoms = 1000             # two concurrent halves
+    x2, p2, _, _ = gen.sample_batch(sizes, None, 1.0, 1.0, seed=5)
+    assert torch.equal(x1, x2) and torch.equal(p1, p2)
+    gen.concurrent_atoms = None             # two shards sampled one after the other under the whole request's plan
+    k = 285
+    xa, pa, _, _ = gen.sample_batch(sizes[:k], None, 1.0, 1.0, seed=5, options=whole)
+    xb, pb, _, _ = gen.sample_batch(sizes[k:], None, 1.0, 1.0, seed=5, atom_offset=29 * k, options=whole)
+    assert torch.equal(torch.cat([xa, xb]), x1) and torch.equal(torch.cat([pa, pb]), p1)
+    # and without the shared plan a shard picks the separate launches: close, not equal
+    xc, pc, _, _ = gen.sample_batch(sizes[:k], None, 1.0, 1.0, seed=5)
+    assert not torch.equal(xc, xa)
+    assert float((xc - xa).abs().max()) <= 1e-4 * max(1.0, float(xa.abs().max()))
+
+
+def test_two_generators_on_two_threads_keep_their_bits():
+    """Per-call options instead of process-wide switches: two generators with different options (fused kernels on
+    the fp32 pipe / separate launches in split-operand mode) sampling at the same time from two host threads produce
+    exactly what each produces alone."""
+    import threading
+    import torch
+    model, gen_a = _model_gen(timesteps=12)
+    from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
+    gen_b = ResearchValidatedGenerator(model)
+    eng = model.engine()
+    gen_a.options = eng.options(gemm_mode=0, chain_mode=2)
+    gen_b.options = eng.options(gemm_mode=1, chain_mode=0)
+    gen_a.concurrent_atoms = gen_b.concurrent_atoms = None
+    sizes_a, sizes_b = [29] * 24, [17, 40, 64, 9, 33] * 3
+
+    def run(gen, sizes, seed, out, stream):
+        with torch.no_grad(), torch.cuda.stream(stream):
+            x, p, _, _ = gen.sample_batch(sizes, None, 1.0, 1.0, seed=seed)
+            stream.synchronize()
+        out.append((x.clone(), p.clone()))
+
+    solo_a, solo_b, both_a, both_b = [], [], [], []
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    run(gen_a, sizes_a, 3, solo_a, sa)
+    run(gen_b, sizes_b, 4, solo_b, sb)
+    for _ in range(2):
+        ta = threading.Thread(target=run, args=(gen_a, sizes_a, 3, both_a, sa))
+        tb = threading.Thread(target=run, args=(gen_b, sizes_b, 4, both_b, sb))
+        ta.start(); tb.start(); ta.join(); tb.join()
+    for got in both_a:
+        assert torch.equal(got[0], solo_a[0][0]) and torch.equal(got[1], solo_a[0][1])
+    for got in both_b:
+        assert torch.equal(got[0], solo_b[0][0]) and torch.equal(got[1], solo_b[0][1])
+    # the two option sets really select different kernels
+    gen_b.options = gen_a.options
+    other = []
+    run(gen_b, sizes_b, 4, other, sb)
+    assert not torch.equal(other[0][0], solo_b[0][0])
