@@ -282,13 +282,29 @@ def leg_config3_train_step(ctx, steps=5, warmup=2, mols_per_rank=512):
         ms, (nout, kin, rows) = eng.time_backward_launch(graph, b.x, b.pos, u, wide_dw_index=1, reps=5)
         flops = 2.0 * nout * kin * rows
         ach = flops / (ms * 1e-3) / 1e12
+        tr3, tr3_src = profile_traffic("train3")
         out["roofline"] = {"kernel": f"gemm_dw_kernel<4> (dW[{nout},{kin}] += dY^T X over {rows} rows: dit2.ffn_up weight gradient)",
                            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms}
+                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_of(tr3, "gemm_dw_kernel<4>"),
+                           "traffic_source": tr3_src,
+                           "traffic_note": "mean over the 12 launches of this kernel in a step (different shapes), "
+                                           "rocprofv3 counters at this leg's shape",
+                           "avg_launch_ms": ms}
     return out
 
 
-def leg_config4_fc_sampling(ctx, mols_per_rank=48, traffic=None):
+def fc_partial_rows(sizes):
+    """Rows of per-slab partial sums the fused edge kernel writes for fully connected molecules: an atom's n - 1
+    incoming edges are consecutive, slabs are 32 edges counted from the molecule's first edge."""
+    rows = 0
+    for n in sizes:
+        d = n - 1
+        for a in range(n):
+            rows += (a * d + d - 1) // 32 - (a * d) // 32 + 1
+    return rows
+
+
+def leg_config4_fc_sampling(ctx, mols_per_rank=48):
     """BASELINE configs[3]: large ligands (65-128 atoms), every ordered atom pair an edge, 1000-step DDPM;
     the global molecule list is cut into contiguous ranges balanced by the sum of n^2."""
     from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
@@ -302,81 +318,130 @@ def leg_config4_fc_sampling(ctx, mols_per_rank=48, traffic=None):
     gen = ResearchValidatedGenerator(model)
     eng = model.engine()
     offset = sum(sizes[:lo])
+    # kernel forms fixed ONCE on the whole request, so that every rank's shard takes the forms (and produces the
+    # bits) of a single call over all molecules
+    plan = eng.plan(sum(sizes), sum(n * (n - 1) for n in sizes), len(sizes), max(sizes))
 
     def one_pass(i):
         with torch.no_grad():
-            x, pos, graph, _ = gen.sample_batch(mine, None, 1.0, 1.0, seed=77 + i, atom_offset=offset, connectivity="full")
+            x, pos, graph, _ = gen.sample_batch(mine, None, 1.0, 1.0, seed=77 + i, atom_offset=offset, connectivity="full",
+                                                options=plan)
             acc = eng.validity_gate(x, pos, graph.mol_ptr, graph.n_mols)
         return x, pos, graph, acc
 
     dt, (x, pos, graph, acc) = ctx.timed(one_pass, 0, 1)
+    # the same loop over its last 20 timesteps only (t = 19 .. 0): the state is still finite at the end of it, so
+    # this figure does not sit on Inf / NaN inputs
+    g2, _ = full_graph(mine, dev)
+    win = 20
+
+    def window(i):
+        with torch.no_grad():
+            xw = eng.philox_normal(g2.n_atoms * 119, 91 + i, 0xFFFFFFFF, 0, offset * 119, 1.0).view(-1, 119)
+            pw = eng.philox_normal(g2.n_atoms * 3, 91 + i, 0xFFFFFFFF, 1, offset * 3, 1.0).view(-1, 3)
+            eng.ddpm_sample(model, g2, xw, pw, None, 1.0, 1.0, n_steps=win, seed=91 + i, atom_offset=offset, options=plan)
+        return xw, pw
+    dtw, (xw, pw) = ctx.timed(window, 1, 3)
     out = {"workload": "configs[3]: 65-128-atom ligands, fully connected (i != j) edges, 1000-step DDPM, fp32, "
                        "molecules sharded by sum n^2, no collectives",
            "molecules": len(sizes), "molecules_rank0": len(mine), "atoms_rank0": graph.n_atoms,
            "edges_rank0": graph.n_edges, "ddpm_steps": T_STEPS, "seconds": dt,
            "molecules_per_s": len(sizes) / dt, "ms_per_reverse_step": dt / T_STEPS * 1e3,
            "finite": bool(torch.isfinite(x).all() and torch.isfinite(pos).all()),
-           "note": "with random-init weights a fully connected ligand of this size leaves the finite range after a few "
-                   "dozen reverse steps (each atom's coordinate update sums over n - 1 neighbours); the CPU oracle does "
-                   "the same step for step (tests/test_gpu_full_edges.py), and the work per step does not depend on the values"}
-    if ctx.rank == 0:      # dominant kernel at this shape: the second edge-MLP GEMM ([E,256] x [256,256] + LayerNorm)
+           "finite_window": {"reverse_steps": win, "calls": 3, "ms_per_reverse_step": dtw / 3 / win * 1e3,
+                             "molecules_per_s_at_1000_steps": len(sizes) / (dtw / 3 / win * T_STEPS),
+                             "finite": bool(torch.isfinite(xw).all() and torch.isfinite(pw).all()),
+                             "note": "timesteps 19..0 from fresh noise, includes each call's set-up (time tables, graph "
+                                     "capture); the state stays finite over this window"},
+           "kernel_forms": plan.as_dict(),
+           "note": "TIMING ONLY for the 1000-step figure: with random-init weights a fully connected ligand of this size "
+                   "leaves the finite range after a few dozen reverse steps (each atom's coordinate update sums over n - 1 "
+                   "neighbours; the CPU oracle does the same step for step, tests/test_gpu_full_edges.py), so most of "
+                   "the 1000 steps run on Inf / NaN inputs; finite_window is the same loop where the state is finite"}
+    if ctx.rank == 0:      # dominant kernel at this shape: the fused edge path of an E(3) layer
+        fc_traffic, fc_src = profile_traffic("fc")
         t_index = torch.full((1,), 500, dtype=torch.int32, device=dev)
-        g2, _ = full_graph(mine, dev)
-        try:     # the fused edge path of an E(3) layer (edge pre-activation, second edge linear + LN, coordinate gate)
-            eng.time_launch("e3_1.edge_chain", g2, x, pos, t_index, reps=2)
-            ms = eng.time_launch("e3_1.edge_chain", g2, x, pos, t_index, reps=5)
-            flops = 2.0 * g2.n_edges * (32 * 256 + 256 * 256 + 256 * 128)
-            name = f"edge_chain_kernel (e3_*.edge_chain, E={g2.n_edges}: K=32 + 256x256 + 256x128 per edge)"
+        xr = torch.randn(g2.n_atoms, 119, device=dev)
+        pr = torch.randn(g2.n_atoms, 3, device=dev)
+        E, N = g2.n_edges, g2.n_atoms
+        try:     # edge pre-activation, second edge linear + LN, coordinate gate (+ per-destination sums)
+            eng.time_launch("e3_1.edge_chain", g2, xr, pr, t_index, reps=2, options=plan)
+            ms = eng.time_launch("e3_1.edge_chain", g2, xr, pr, t_index, reps=5, options=plan)
+            flops = 2.0 * E * (32 * 256 + 256 * 256 + 256 * 128)
+            name = (f"edge_chain_kernel (e3_*.edge_chain, E={E}: K=32 + 256x256 + 256x128 per edge"
+                    + (", per-destination message sums inside the kernel)" if plan.edge_reduce else ")"))
+            needle = ("edge_chain_kernel<false, 0, true>",) if plan.edge_reduce else ("edge_chain_kernel<false, 0>",)
         except Exception:   # noqa: BLE001  (separate launches: the second edge-MLP GEMM is the largest)
-            eng.time_launch("e3_1.edge_mlp2", g2, x, pos, t_index, reps=2)
-            ms = eng.time_launch("e3_1.edge_mlp2", g2, x, pos, t_index, reps=5)
-            flops = 2.0 * g2.n_edges * 256 * 256
-            name = f"gemm_cs_kernel<APtrPlain, EpiLN> (e3_*.edge_mlp2, M={g2.n_edges} K=256 N=256)"
+            eng.time_launch("e3_1.edge_mlp2", g2, xr, pr, t_index, reps=2, options=plan)
+            ms = eng.time_launch("e3_1.edge_mlp2", g2, xr, pr, t_index, reps=5, options=plan)
+            flops = 2.0 * E * 256 * 256
+            name = f"gemm_cs_kernel<APtrPlain, EpiLN> (e3_*.edge_mlp2, M={E} K=256 N=256)"
+            needle = ("gemm_cs_kernel<", "EpiLN<0, 0, false>")
         ach = flops / (ms * 1e-3) / 1e12
         out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms}
-        ms_agg = eng.time_launch("e3_1.aggregate", g2, x, pos, t_index, reps=5)
-        E, N = g2.n_edges, g2.n_atoms
-        bytes_agg = E * 1024.0 + N * 1024.0 + E * 32.0 + N * 36.0
-        out["roofline_aggregation"] = {"kernel": "k_aggregate", "bound": "hbm", "achieved": bytes_agg / (ms_agg * 1e-3) / 1e9,
+                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_of(fc_traffic, *needle),
+                           "traffic_source": fc_src, "avg_launch_ms": ms}
+        ms_agg = eng.time_launch("e3_1.aggregate", g2, xr, pr, t_index, reps=5, options=plan)
+        if plan.edge_reduce:
+            rows = fc_partial_rows(mine)
+            bytes_agg = rows * 1024.0 + N * 1024.0 + E * 32.0 + N * 36.0
+            kname = (f"k_aggregate<true> (e3_*.aggregate on {rows} per-slab partial rows: the [E,256] messages are summed "
+                     "per destination inside edge_chain_kernel and never reach memory)")
+            needle = ("k_aggregate<true>",)
+        else:
+            bytes_agg = E * 1024.0 + N * 1024.0 + E * 32.0 + N * 36.0
+            kname, needle = "k_aggregate", ("k_aggregate<false>",)
+        out["roofline_aggregation"] = {"kernel": kname, "bound": "hbm", "achieved": bytes_agg / (ms_agg * 1e-3) / 1e9,
                                        "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": bytes_agg / (ms_agg * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
-                                       "avg_launch_ms": ms_agg}
+                                       "frac": bytes_agg / (ms_agg * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                       "traffic": traffic_of(fc_traffic, *needle), "traffic_source": fc_src,
+                                       "algorithmic_bytes": bytes_agg, "avg_launch_ms": ms_agg,
+                                       "message_tensor_bytes_avoided": 2.0 * E * 1024.0 if plan.edge_reduce else 0.0}
     return out
 
 
 def leg_config5_ragged_split_sweep(ctx, mols_per_rank=1024):
     """BASELINE configs[4]: mixed-size ragged ligands (10-128 atoms, bond templates), 1000-step DDPM with
     the MLP GEMMs on the bf16 matrix pipe (split-operand mode); a bounded slice of the 100k-molecule
-    sweep, packed into batches of at most 32768 atoms, sharded by atoms."""
+    sweep, packed into batches of at most 32768 atoms, sharded by atoms.  The full sweep, run once on one
+    GPU (tools/config5_sweep.py), is reported from its committed record."""
+    import numpy as np
     from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
     from diffusion_model_ligandmol_generation_amd.parallel import shard_ranges
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from config5_sweep import fingerprint
     dev = ctx.dev
     sizes = uniform_sizes(mols_per_rank * ctx.world, 10, 128, 555)
-    lo, hi = shard_ranges(sizes, ctx.world, cost="atoms")[ctx.rank]
+    lo, hi = shard_ranges(sizes, ctx.world, cost="atoms", align_atoms=32768)[ctx.rank]
     mine = sizes[lo:hi]
     model = build_model(dev, 128)
     gen = ResearchValidatedGenerator(model)
     eng = model.engine()
-    prev = eng.set_split_gemm(True)
-    try:
-        def one_pass(i):
-            res, flags = gen.sample_many(mine, None, 1.0, 1.0, use_ddim=False, seed=31 + i, atom_offset=sum(sizes[:lo]))
-            return res, flags
-        dt, (res, flags) = ctx.timed(one_pass, 0, 1)
-    finally:
-        eng.set_split_gemm(prev)
+    gen.options = eng.options(gemm_mode=1)      # per call: the process-wide GEMM mode is left alone
+
+    def one_pass(i):
+        res, flags = gen.sample_many(mine, None, 1.0, 1.0, use_ddim=False, seed=31 + i, atom_offset=sum(sizes[:lo]))
+        return res, flags
+    dt, (res, flags) = ctx.timed(one_pass, 0, 1)
     rate = len(sizes) / dt
-    import numpy as np
-    return {"workload": "configs[4]: ragged 10-128-atom template ligands, 1000-step DDPM, MLP GEMMs as split-operand bf16 "
-                        "MFMA (fp32 accumulate), batches of <= 32768 atoms, results copied to the host",
-            "molecules": len(sizes), "atoms": int(sum(sizes)), "ddpm_steps": T_STEPS, "seconds": dt,
-            "molecules_per_s": rate, "extrapolated_100k_sweep_s": 100000.0 / rate,
-            "accepted_rank0": int(sum(flags)),
-            "finite": bool(all(np.isfinite(r[0]).all() and np.isfinite(r[1]).all() for r in res))}
+    finite = [bool(np.isfinite(r[0]).all() and np.isfinite(r[1]).all()) for r in res]
+    prints = {fingerprint(r[0], r[1]) for r, ok in zip(res, finite) if ok}
+    out = {"workload": "configs[4]: ragged 10-128-atom template ligands, 1000-step DDPM, MLP GEMMs as split-operand bf16 "
+                       "MFMA (fp32 accumulate), batches of <= 32768 atoms, results copied to the host",
+           "molecules": len(sizes), "atoms": int(sum(sizes)), "ddpm_steps": T_STEPS, "seconds": dt,
+           "molecules_per_s": rate, "extrapolated_100k_sweep_s": 100000.0 / rate,
+           "accepted_rank0": int(sum(flags)), "acceptance_rate_rank0": float(sum(flags)) / max(1, len(mine)),
+           "finite_rank0": int(sum(finite)), "finite": bool(all(finite)),
+           "distinct_among_finite_rank0": len(prints) / max(1, sum(finite))}
+    path = os.path.join(ROOT, "profiles", "r3_config5_sweep.json")
+    if ctx.rank == 0 and os.path.exists(path):
+        with open(path) as fh:
+            out["full_sweep_recorded"] = dict(json.loads(fh.readline()), source="profiles/r3_config5_sweep.json "
+                                              "(tools/config5_sweep.py, one MI355X, not re-run by this bench)")
+    return out
 
 
-def run_extras(ctx, extras, traffic):
+def run_extras(ctx, extras):
     """Every leg on every rank (their barriers stay matched); a failing leg reports its error."""
     legs = (("config3_train_step", lambda: leg_config3_train_step(ctx)),
             ("config4_fc_sampling", lambda: leg_config4_fc_sampling(ctx)),
@@ -437,8 +502,8 @@ def run_rank(args):
 
     # GEMM mode of the library: fp32 matrix pipe unless LIGDIFF_GEMM_SPLIT=1 is in the environment.
     # The headline run uses that mode; the other mode is timed afterwards and reported beside it.
-    split_mode = eng.set_split_gemm(False)
-    eng.set_split_gemm(split_mode)
+    split_mode = os.environ.get("LIGDIFF_GEMM_SPLIT", "0")[:1] not in ("", "0")
+    gen.options = eng.options(gemm_mode=int(split_mode))      # per call; no process-wide switch is touched
     log(ctx, f"headline: {args.warmup} warm-up + {args.steps} timed passes of {MOLS_PER_GPU} molecules x {T_STEPS} steps ...")
     dt, accepted, x, pos = timed_run(args.warmup, args.steps)
     pass_seconds = [round(b - a, 4) for a, b in zip(pass_ends, pass_ends[1:])]
@@ -447,16 +512,17 @@ def run_rank(args):
     # (every rank runs it, so the barriers inside stay matched; a failure here must not lose the headline)
     alt_error = None
     try:
-        eng.set_split_gemm(not split_mode)
+        gen.options = eng.options(gemm_mode=int(not split_mode))
         dt_alt, _, x_alt, pos_alt = timed_run(1, args.steps)
     except Exception as e:   # noqa: BLE001
         alt_error = repr(e)
     finally:
-        eng.set_split_gemm(split_mode)
+        gen.options = eng.options(gemm_mode=int(split_mode))
 
     out = None
     log(ctx, "rooflines / CPU baselines ...")
     traffic, traffic_src = profile_traffic()
+    split_traffic, split_src = profile_traffic("split")
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * MOLS_PER_GPU * args.steps / dt
@@ -466,15 +532,14 @@ def run_rank(args):
         graph, _, _ = template_graph(sizes, dev)
 
         def ffn_up_roofline(split):
-            eng.set_split_gemm(split)
+            ro = eng.plan_graph(graph, eng.options(gemm_mode=int(split)))
             if not split:
                 # fp32 pipe: the dominant launch is the fused attention-layer tail (out-projection, feed-forward
                 # block, next layer's pre-norm and in-projection); LIGDIFF_CHAIN=0 brings the separate
                 # launches back and the feed-forward up-projection is then the largest one
                 try:
-                    eng.time_launch("dit1.chain", graph, x, pos, t_index, reps=2)    # warm
-                    ms = eng.time_launch("dit1.chain", graph, x, pos, t_index, reps=10)
-                    eng.set_split_gemm(split_mode)
+                    eng.time_launch("dit1.chain", graph, x, pos, t_index, reps=2, options=ro)    # warm
+                    ms = eng.time_launch("dit1.chain", graph, x, pos, t_index, reps=10, options=ro)
                     # 29-atom ligands take the molecule-per-wave form: the layer's own in-projection and attention
                     # (8 heads x (K Q^T + V^T P^T) on 32 x 32 x 32 tiles per molecule) sit in front of the out-projection
                     mol_form = ATOMS <= 32 and os.environ.get("LIGDIFF_CHAIN_MOL", "1")[:1] != "0"
@@ -498,9 +563,8 @@ def run_rank(args):
                             "traffic_source": traffic_src, "avg_launch_ms": ms}
                 except Exception:   # noqa: BLE001  (label not present: chain kernels switched off)
                     pass
-            eng.time_launch("dit1.ffn_up", graph, x, pos, t_index, reps=2)           # warm
-            ms = eng.time_launch("dit1.ffn_up", graph, x, pos, t_index, reps=10)
-            eng.set_split_gemm(split_mode)
+            eng.time_launch("dit1.ffn_up", graph, x, pos, t_index, reps=2, options=ro)           # warm
+            ms = eng.time_launch("dit1.ffn_up", graph, x, pos, t_index, reps=10, options=ro)
             flops = 2.0 * N * 256 * 1024
             if not split:
                 ach = flops / (ms * 1e-3) / 1e12
@@ -514,8 +578,8 @@ def run_rank(args):
             return {"kernel": "gemm_cs_split_kernel<APtrPlain, EpiBiasAct<8,GELU>> (dit*.ffn_up, M=29696 K=256 N=1024)",
                     "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-                    "traffic": traffic_of(traffic, "gemm_cs_split_kernel<", "EpiBiasAct<8, 1, false, false>"),
-                    "traffic_source": traffic_src, "avg_launch_ms": ms,
+                    "traffic": traffic_of(split_traffic, "gemm_cs_split_kernel<", "EpiBiasAct<8, 1, false"),
+                    "traffic_source": split_src, "avg_launch_ms": ms,
                     "fp32_equivalent_tflops": flops / (ms * 1e-3) / 1e12,
                     "note": "achieved counts the six bf16 MFMA products issued per fp32 product"}
         roofline = ffn_up_roofline(split_mode)
@@ -597,7 +661,7 @@ def run_rank(args):
         timer.daemon = True
         timer.start()
         ctx.fence()
-        run_extras(ctx, extras, traffic)
+        run_extras(ctx, extras)
         timer.cancel()
         log(ctx, "extras done")
         emit()

@@ -82,7 +82,10 @@ void dit_chain_kernel(DitChainArgs p) {
     const int mc = mol < p.B ? mol : p.B - 1;
     const int a0 = p.mol_ptr[mc];
     n_mol = p.mol_ptr[mc + 1] - a0;
-    rr = a0 + (fi < n_mol ? fi : n_mol - 1);
+    // (an empty molecule: every lane invalid, rows read from a valid address; its all-masked softmax stays in
+    // this wave's registers and is never stored)
+    rr = a0 + (fi < n_mol ? fi : (n_mol > 0 ? n_mol - 1 : 0));
+    rr = rr < p.M ? rr : p.M - 1;
     valid = mol < p.B && fi < n_mol;
   } else {
     const int row = blockIdx.x * 128 + cl.wave * 32 + fi;

@@ -177,9 +177,16 @@ static __device__ __align__(256) int32_t scratch[4 * (PACK_STATIC_MAX_ATOMS + 1)
 static std::mutex g_scratch_mutex;
 static int32_t* g_scratch_ptr[PACK_MAX_DEVICES];   // device address of `scratch` on each device, once resolved
 
-static int scratch_of_current_device(int32_t** out) {
+// The array is resolved for the CURRENT device; a stream of another device would hand its kernels the wrong
+// device's address, so such a call is refused.
+static int scratch_of_current_device(int32_t** out, hipStream_t stream) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PACK_MAX_DEVICES) return LIGDIFF_ERR_LAUNCH;
+  if (stream != nullptr) {
+    hipDevice_t sdev = -1;
+    if (hipStreamGetDevice(stream, &sdev) != hipSuccess) return LIGDIFF_ERR_LAUNCH;
+    if ((int)sdev != dev) return LIGDIFF_ERR_ARG;
+  }
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (g_scratch_ptr[dev] == nullptr) {
     void* p = nullptr;
@@ -199,7 +206,7 @@ extern "C" int ligdiff_pack_csr_static(const int64_t* edge_index, int64_t E, con
   if (rc) return rc;
   if (N > PACK_STATIC_MAX_ATOMS) return LIGDIFF_ERR_WORKSPACE;   // beyond the static array: use ligdiff_pack_csr
   int32_t* counters = nullptr;
-  rc = scratch_of_current_device(&counters);
+  rc = scratch_of_current_device(&counters, (hipStream_t)stream);
   if (rc) return rc;
   // pack_csr_run zeroes the 4 (N + 1) counters it uses before counting, so what an earlier call left
   // behind (also beyond this call's N) never enters a result

@@ -206,25 +206,53 @@ class ResearchAccurateDiffusionModel(nn.Module):
             losses["property"] = property_loss
             losses["total"] = losses["total"] + loss_weights["property"] * property_loss
         if cons is not None:                                                                   # model1.py:842-886
+            # Each term sits in its own try / except in the reference: a label whose shape does not fit is skipped,
+            # not fatal (only shape / type errors are swallowed here; anything else still raises).  The consistency
+            # outputs carry no gradient in this build, so these terms add their VALUE to losses['total'] (as the
+            # reference reports it) but optimising that total does not train the consistency module through them:
+            # said once per process when a label is present.
             atom_logits, _, valency_pred, adjacency = cons
+            skip = (RuntimeError, ValueError, IndexError, TypeError)
+            used = False
             if atom_logits is not None and hasattr(data, "true_atom_types"):
-                al = F.cross_entropy(atom_logits, data.true_atom_types.to(dev))
-                losses["atom_type"] = al
-                losses["total"] = losses["total"] + loss_weights["atom_type"] * al
-                metrics["atom_accuracy"] = (atom_logits.argmax(-1) == data.true_atom_types.to(dev)).float().mean().item()
+                try:
+                    al = F.cross_entropy(atom_logits, data.true_atom_types.to(dev))
+                    acc = (atom_logits.argmax(-1) == data.true_atom_types.to(dev)).float().mean().item()
+                    losses["atom_type"] = al
+                    losses["total"] = losses["total"] + loss_weights["atom_type"] * al
+                    metrics["atom_accuracy"] = acc
+                    used = True
+                except skip:
+                    pass
             if valency_pred is not None and hasattr(data, "valency_labels"):
-                lab = data.valency_labels.to(dev).float()
-                vl = F.mse_loss(valency_pred, lab)
-                losses["valency"] = vl
-                losses["total"] = losses["total"] + loss_weights["valency"] * vl
-                metrics["valency_mae"] = F.l1_loss(valency_pred, lab).item()
+                try:
+                    lab = data.valency_labels.to(dev).float()
+                    vl = F.mse_loss(valency_pred, lab)
+                    mae = F.l1_loss(valency_pred, lab).item()
+                    losses["valency"] = vl
+                    losses["total"] = losses["total"] + loss_weights["valency"] * vl
+                    metrics["valency_mae"] = mae
+                    used = True
+                except skip:
+                    pass
             if adjacency is not None and hasattr(data, "adjacency_matrix"):
-                pa = adjacency.reshape(-1, 5)
-                ta = data.adjacency_matrix.to(dev).reshape(-1, 5).argmax(-1)
-                adl = F.cross_entropy(pa, ta)
-                losses["adjacency"] = adl
-                losses["total"] = losses["total"] + loss_weights["adjacency"] * adl
-                metrics["adjacency_accuracy"] = (pa.argmax(-1) == ta).float().mean().item()
+                try:
+                    pa = adjacency.reshape(-1, 5)
+                    ta = data.adjacency_matrix.to(dev).reshape(-1, 5).argmax(-1)
+                    adl = F.cross_entropy(pa, ta)
+                    acc = (pa.argmax(-1) == ta).float().mean().item()
+                    losses["adjacency"] = adl
+                    losses["total"] = losses["total"] + loss_weights["adjacency"] * adl
+                    metrics["adjacency_accuracy"] = acc
+                    used = True
+                except skip:
+                    pass
+            if used and not getattr(ResearchAccurateDiffusionModel, "_warned_detached_consistency", False):
+                import warnings
+                ResearchAccurateDiffusionModel._warned_detached_consistency = True
+                warnings.warn("compute_loss: the atom_type / valency / adjacency terms are computed from detached "
+                              "consistency outputs: they are part of losses['total'] as a value, but its backward does "
+                              "not reach the consistency module (model1.py:842-886 backpropagates through them)")
         return losses, metrics
 
     def sample(self, num_samples=1, target_properties=None, guidance_scale=1.0, num_steps=100, max_atoms=30,

@@ -28,7 +28,7 @@ LOSS_TERMS = ("edm_coordinate", "edm_preconditioning", "pilot_property", "dit_at
 
 class ResearchAccurateTrainer:
     def __init__(self, model, train_loader, val_loader, test_loader, chemical_constants=None, lr=2e-4,
-                 weight_decay=1e-5, debug_mode=False, process_group=None, device=None):
+                 weight_decay=1e-5, debug_mode=False, process_group=None, device=None, reference_collate_quirk=False):
         if device is None:
             device = next(model.parameters()).device
             if device.type != "cuda":
@@ -39,6 +39,11 @@ class ResearchAccurateTrainer:
         self.model = model.to(device)
         self.train_loader, self.val_loader, self.test_loader = train_loader, val_loader, test_loader
         self.debug_mode = debug_mode
+        # True: take ``batch.properties`` exactly as the reference's own loaders deliver them (data_utils.py:904-914
+        # stores 14 values per molecule as a 1-D vector, PyG collate concatenates them to [14 B]) and do with them
+        # what train.py:327-343 / :388-397 does: one row for every molecule, PILOT loss family skipped.  False: such
+        # a tensor is refused, because that behaviour is almost certainly not what a caller wants.
+        self.reference_collate_quirk = reference_collate_quirk
         self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay,
                                            betas=(0.9, 0.999), eps=1e-8)                      # train.py:47-53
         self.warmup_steps = 1000
@@ -56,12 +61,24 @@ class ResearchAccurateTrainer:
         self.group = process_group
         self.world = 1
         self.rank = 0
+        self.count_group = None
+        self.dp_seed_base = 0
         if process_group is not None:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
             # the score network's backward sums its parameter gradients over this group (one collective
             # on the flat gradient buffer it already owns)
             self.model.grad_allreduce_group = process_group
+            # Per-step bookkeeping of the sharded batch (each rank's atom / molecule count) is exchanged between the
+            # HOST processes: with an RCCL main group a gloo group over the same ranks carries it, so no step reads a
+            # device tensor back before its forward is enqueued (a device all-gather + .cpu() would drain the GPU).
+            # The dropout key of step k is base + k with rank 0's base, broadcast once here.
+            self.count_group = process_group
+            if dist.get_backend(process_group) == "nccl":
+                self.count_group = dist.new_group(ranks=dist.get_process_group_ranks(process_group), backend="gloo")
+            base = torch.randint(0, 1 << 61, (1,), dtype=torch.int64)
+            dist.broadcast(base, src=dist.get_global_rank(process_group, 0), group=self.count_group)
+            self.dp_seed_base = int(base.item())
 
     def _edm_lr_schedule(self, step):
         """train.py:110-117."""
@@ -105,6 +122,7 @@ class ResearchAccurateTrainer:
                                           _ptr(coef), _ptr(c_noise), _ptr(noisy), _ptr(pre_pos), _stream()),
                   "ligdiff_edm_prepare")
         properties = None
+        pilot_loss = True
         if hasattr(batch, "properties") and batch.properties is not None:              # train.py:327-343
             properties = batch.properties.to(dev).float()
             if properties.dim() == 1:
@@ -112,8 +130,19 @@ class ResearchAccurateTrainer:
             if properties.shape[0] != B:
                 properties = properties.repeat(B, 1) if properties.shape[0] == 1 else properties[:B]
             if properties.shape[1] != 15:
-                raise ValueError("batch.properties must be [B,15] (the reference's [14B] collate quirk is not "
-                                 "reproduced: its PILOT loss is skipped on a shape mismatch)")
+                if not self.reference_collate_quirk:
+                    raise ValueError("batch.properties must be [B,15]; the reference's own loaders deliver [14 B] "
+                                     "(data_utils.py:904-914 + PyG collate), which train.py:327-343 turns into one "
+                                     "row for every molecule with the PILOT loss skipped: pass "
+                                     "reference_collate_quirk=True to the trainer to get exactly that")
+                if properties.shape[1] < 8:
+                    raise ValueError("batch.properties needs at least the 8 columns the PILOT encoders read")
+                # F.mse_loss(prop_pred [B,15], properties [B,w]) raises inside the try block of train.py:388-397:
+                # the family contributes nothing; the model reads columns 0..7 only (model1.py:342-345)
+                pilot_loss = False
+                p15 = properties.new_zeros(B, 15)
+                p15[:, :8] = properties[:, :8]
+                properties = p15
             if training:
                 null_rand = draws["null_rand"].to(dev) if "null_rand" in draws else torch.rand(B, device=dev)
                 properties = properties.clone()
@@ -124,15 +153,13 @@ class ResearchAccurateTrainer:
         n_atoms_g, n_mols_g, mol_off, atom_off = N, B, 0, 0
         if self.group is not None:
             import torch.distributed as dist
-            cdev = dev if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
-            seed_here = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
-            cnt = torch.tensor([N, B, seed_here], device=cdev, dtype=torch.int64)
+            cnt = torch.tensor([N, B], dtype=torch.int64)             # host tensors, host-side collective
             allc = [torch.zeros_like(cnt) for _ in range(self.world)]
-            dist.all_gather(allc, cnt, group=self.group)
-            allc = torch.stack(allc).cpu()
+            dist.all_gather(allc, cnt, group=self.count_group)
+            allc = torch.stack(allc)
             n_atoms_g, n_mols_g = int(allc[:, 0].sum()), int(allc[:, 1].sum())
             mol_off, atom_off = int(allc[:self.rank, 1].sum()), int(allc[:self.rank, 0].sum())
-            shared_seed = int(allc[0, 2])     # every rank keys its dropout masks with rank 0's draw
+            shared_seed = (self.dp_seed_base + self.step_count) & ((1 << 62) - 1)   # the same key on every rank
 
         class _Data:
             pass
@@ -153,9 +180,11 @@ class ResearchAccurateTrainer:
 
         rot_mols = max(0, min(2, n_mols_g) - mol_off)
         rot_mols = min(rot_mols, B)
-        st = _Ctx(eng=eng, graph=graph, pos=pos, noise=noise, noisy=noisy, coef=coef, props=properties,
+        loss_props = properties if pilot_loss else None      # what the PILOT loss family sees
+        st = _Ctx(eng=eng, graph=graph, pos=pos, noise=noise, noisy=noisy, coef=coef, props=loss_props,
                   rot_mols=rot_mols, n_atoms_global=n_atoms_g, n_mols_global=n_mols_g, group=self.group)
-        out = EDMLossFunction.apply(st, atom_pred, pos_pred, prop_pred if properties is not None else None)
+        out = EDMLossFunction.apply(st, atom_pred, pos_pred, prop_pred if loss_props is not None else None)
+        properties = loss_props
         losses = {"total_loss": out[8]}
         vals = out.detach()
         for i, k in enumerate(LOSS_TERMS):

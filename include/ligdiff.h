@@ -120,8 +120,9 @@ int ligdiff_pack_csr(const int64_t* edge_index, int64_t n_edges, const int64_t* 
  * the call performs no hipMalloc / hipFree and needs none made for it.  n_atoms above
  * LIGDIFF_PACK_STATIC_MAX_ATOMS returns LIGDIFF_ERR_WORKSPACE (use ligdiff_pack_csr).  All calls on one
  * GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race;
- * calls on different GPUs do not interact.  The first call on a device resolves the array's device
- * address (hipGetSymbolAddress) and should be made outside stream capture.
+ * calls on different GPUs do not interact.  `stream` must belong to the CURRENT device (the array is resolved
+ * for the current device; a stream of another device returns LIGDIFF_ERR_ARG).  The first call on a device
+ * resolves the array's device address (hipGetSymbolAddress) and should be made outside stream capture.
  * No counterpart in the reference (it packs nothing; PyG collate + per-call index arithmetic,
  * model1.py:88-112, main.py:205-212).
  */

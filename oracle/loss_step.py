@@ -27,6 +27,20 @@ def _mean_pool(v, batch, B):
     return s / c.unsqueeze(-1)
 
 
+def batch_properties(properties, B):
+    """train.py:327-337: what the loss step makes of ``batch.properties``.  Returns (properties [B, w], pilot_loss):
+    a 1-D tensor becomes one row repeated for every molecule, a tensor with another row count is cut to B rows.
+    The reference's own loader stores 14 values per molecule as a 1-D vector (data_utils.py:904-914), which PyG's
+    collate concatenates to [14 B]: every molecule is then conditioned on that row (the model reads its first
+    eight columns, model1.py:342-345) and F.mse_loss(prop_pred [B,15], properties [B,w]) raises for w != 15 inside
+    the try block of train.py:388-397, so the PILOT family contributes nothing: pilot_loss = False."""
+    if properties.dim() == 1:
+        properties = properties.unsqueeze(0)
+    if properties.shape[0] != B:
+        properties = properties.repeat(B, 1) if properties.shape[0] == 1 else properties[:B]
+    return properties, properties.shape[1] == 15
+
+
 def loss_step(sd, x, pos, edge_index, batch, u, noise, properties=None, null_rand=None,
               training=True, max_atoms=100, sigma_min=0.002, sigma_max=80.0, sigma_data=0.5, shard=None,
               dropout=None):
@@ -47,15 +61,16 @@ def loss_step(sd, x, pos, edge_index, batch, u, noise, properties=None, null_ran
     w = edm_loss_weight(sigma, sigma_data)
     noisy = pos + sigma[batch].unsqueeze(-1) * noise                     # train.py:305-307
     pre = noisy * c_in[batch].unsqueeze(-1)                              # train.py:311-312
-    props = None
+    props, pilot_loss = None, True
     if properties is not None:
-        props = properties
+        props, pilot_loss = batch_properties(properties, B)              # train.py:327-337
         if training:                                                     # train.py:340-343
             props = props.clone()
             props[null_rand < 0.1] = 0.0
     atom_pred, pos_pred, prop_pred = score_network_forward(
         sd, x, pre, edge_index, batch, c_noise, props, max_atoms=max_atoms, pad_to_max_atoms=False, dropout=dropout)
-    L, den = loss_terms(atom_pred, pos_pred, prop_pred, pos, noise, noisy, c_skip, c_out, w, batch, props)
+    L, den = loss_terms(atom_pred, pos_pred, prop_pred, pos, noise, noisy, c_skip, c_out, w, batch,
+                        props if pilot_loss else None)
     aux = {"sigma": sigma, "denoised_pos": den, "atom_pred": atom_pred, "pos_pred": pos_pred,
            "prop_pred": prop_pred}
     return L, aux

@@ -265,3 +265,44 @@ def test_checkpoint_round_trip_has_the_reference_layout(tmp_path, monkeypatch):
         a2, p2, r2, _ = tr.model(d, t)
     assert torch.equal(a1, a2) and torch.equal(p1, p2) and torch.equal(r1, r2)
     torch.testing.assert_close(a1.cpu(), torch.from_numpy(f["int_noprop_atom"]), rtol=1e-4, atol=2e-5)
+
+
+def test_reference_loader_batches_train_as_in_the_reference():
+    """The reference's own loaders deliver ``properties`` collated to [14 B] and one-atom molecules with a [[0, 0]]
+    self-loop (data_utils.py:889-914).  With reference_collate_quirk=True the trainer does with them what
+    train.py:327-343 / :388-397 does (one row conditions every molecule, PILOT loss skipped): losses and gradients
+    against the reference's own (tests/golden/quirk.npz); without the switch such a batch is refused."""
+    from diffusion_model_ligandmol_generation_amd.train import ResearchAccurateTrainer
+    f = golden("quirk.npz")
+    m = no_dropout(copy.deepcopy(seed0_model())).cuda().train()
+    batch = Bag(x=torch.from_numpy(f["x"]).cuda(), pos=torch.from_numpy(f["pos"]).cuda(),
+                edge_index=torch.from_numpy(f["edge_index"]).cuda(), batch=torch.from_numpy(f["batch"]).cuda(),
+                properties=torch.from_numpy(f["props_flat"]).cuda())
+    draws = {"u": torch.from_numpy(f["u"]), "noise": torch.from_numpy(f["noise"]), "null_rand": torch.from_numpy(f["null_rand"])}
+    with pytest.raises(ValueError, match="reference_collate_quirk"):
+        ResearchAccurateTrainer(m, [], [], [])._compute_research_exact_loss(batch, training=True, draws=draws)
+    tr = ResearchAccurateTrainer(m, [], [], [], reference_collate_quirk=True)
+    tr.optimizer.zero_grad()
+    losses = tr._compute_research_exact_loss(batch, training=True, draws=draws)
+    assert "pilot_property" not in losses and float(losses["pilot_total"]) == 0.0
+    n = 0
+    for k, v in losses.items():
+        if f"loss_{k}" in f.files:
+            ref = float(f[f"loss_{k}"])
+            assert abs(float(v) - ref) <= 1e-4 * max(abs(ref), 1e-3), (k, float(v), ref)
+            n += 1
+    assert n >= 10
+    losses["total_loss"].backward()
+    gsq = 0.0
+    for name, p in tr.model.named_parameters():
+        key = f"gradsum_{name}"
+        assert (p.grad is not None) == (key in f.files), name     # same set of parameters receives a gradient
+        if p.grad is None:
+            continue
+        g = p.grad.double()
+        gsq += float((g ** 2).sum())
+        assert abs(float((g ** 2).sum()) - float(f[key][2])) <= 5e-3 * float(f[key][2]) + 1e-12, name
+        if f"grad_{name}" in f.files:
+            ref = torch.from_numpy(f[f"grad_{name}"])
+            assert float((p.grad.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, name
+    assert abs(gsq ** 0.5 - float(f["gradnorm"])) <= 1e-3 * float(f["gradnorm"])

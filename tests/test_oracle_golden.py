@@ -269,3 +269,46 @@ def test_oracle_train_mode_dropout_matches_reference(tag):
     k = "dit_layers.1.ff_network.0.bias"
     diff = float((sd0[k].grad - sd[k].grad).abs().max()) / float(sd[k].grad.abs().max())
     assert diff > 0.05, diff
+
+
+def test_reference_loader_shapes_match_reference():
+    """tests/golden/quirk.npz: the shapes the reference's OWN data pipeline delivers - ``properties`` collated to
+    [14 B] (train.py:327-343: one row for every molecule, PILOT loss skipped) and one-atom molecules with the [[0, 0]]
+    self-loop of data_utils.py:893-895 or with no edge - through the oracle: eval forward, loss terms, gradients."""
+    f = golden("quirk.npz")
+    base = seed0_state_dict()
+    x, pos, ei, b, t = (torch.from_numpy(f["fwd_" + k]) for k in ("x", "pos", "edge_index", "batch", "t"))
+    with torch.no_grad():
+        a, p, r = oracle.score_network_forward(base, x, pos, ei, b, t, None)
+    torch.testing.assert_close(a, torch.from_numpy(f["fwd_atom"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(p, torch.from_numpy(f["fwd_pos_pred"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(r, torch.from_numpy(f["fwd_prop"]), rtol=1e-4, atol=1e-5)
+    from conftest import seed0_model
+    pnames = {n for n, _ in seed0_model().named_parameters()}
+    sd = {k: (v.requires_grad_(True) if k in pnames else v) for k, v in base.items()}
+    x, pos, ei, b = (torch.from_numpy(f[k]) for k in ("x", "pos", "edge_index", "batch"))
+    L, _ = oracle.loss_step(sd, x, pos, ei, b, torch.from_numpy(f["u"]), torch.from_numpy(f["noise"]),
+                            torch.from_numpy(f["props_flat"]), torch.from_numpy(f["null_rand"]))
+    assert "pilot_property" not in L and float(L["pilot_total"]) == 0.0 and float(f["loss_pilot_total"]) == 0.0
+    assert "loss_pilot_property" not in f.files
+    n_checked = 0
+    for k, v in L.items():
+        key = f"loss_{k}"
+        if key in f.files:
+            assert abs(float(v.detach()) - float(f[key])) <= 1e-5 * max(1e-3, abs(float(f[key]))), k
+            n_checked += 1
+    assert n_checked >= 10
+    L["total_loss"].backward()
+    gsq = 0.0
+    for k, v in sd.items():
+        if v.grad is None:
+            assert f"gradsum_{k}" not in f.files or float(f[f"gradsum_{k}"][1]) == 0.0, k
+            continue
+        gsq += float((v.grad.double() ** 2).sum())
+        if f"grad_{k}" in f.files:
+            ref = torch.from_numpy(f[f"grad_{k}"])
+            assert float((v.grad - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7, k
+    assert abs(gsq ** 0.5 - float(f["gradnorm"])) <= 1e-5 * float(f["gradnorm"])
+    # the property encoders are trained through the conditioning even though their loss is skipped
+    assert sd["property_guidance.property_encoders.0.0.weight"].grad is not None
+    assert sd["property_output.3.weight"].grad is None

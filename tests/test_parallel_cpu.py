@@ -29,6 +29,27 @@ def test_shard_ranges_cover_and_balance():
     assert shard_ranges([7, 7], 2) == [(0, 1), (1, 2)]
 
 
+def test_shard_ranges_stay_off_the_extra_round():
+    """2 x 1130 ligands of 29 atoms on two ranks: 32 770 atoms per rank is 257 row blocks of 128, one more round of
+    the fused kernels than 256; with align_atoms the first rank keeps 1129 ligands (32 741 atoms) and the
+    remainder moves on (the last rank takes what is left).  Ranges still cover and stay contiguous."""
+    sizes = [29] * 2260
+    plain = shard_ranges(sizes, 2)
+    assert plain == [(0, 1130), (1130, 2260)]
+    r = shard_ranges(sizes, 2, align_atoms=32768)
+    assert r[0] == (0, 1129) and r[1] == (1129, 2260)
+    rng = np.random.RandomState(1)
+    sizes = rng.randint(10, 129, size=4000).tolist()
+    for world in (2, 4, 8):
+        r = shard_ranges(sizes, world, align_atoms=32768)
+        assert r[0][0] == 0 and r[-1][1] == len(sizes) and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+        assert all(hi > lo for lo, hi in r)
+        for lo, hi in r[:-1]:
+            atoms = sum(sizes[lo:hi])
+            over = atoms % 32768
+            assert atoms < 32768 or over == 0 or over > 0.04 * 32768
+
+
 def test_sharded_loss_equals_global_batch_loss():
     f = golden("loss_step.npz")
     tag = "prop"
