@@ -96,6 +96,7 @@ SIGNATURES = {
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                          C.c_void_p, C.POINTER(Dropout)]),
     "ligdiff_options_init": (None, [C.POINTER(Options)]),
+    "ligdiff_default_options": (None, [C.POINTER(Options)]),
     "ligdiff_plan": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.POINTER(Options), C.POINTER(Options)]),
     "ligdiff_forward_workspace_bytes_opt": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32, C.c_int, C.POINTER(Options)]),
     "ligdiff_forward_opt": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -14,24 +14,41 @@
 #include "weights.h"
 
 struct BwdLayout {
-  size_t dxa, n256b, n256c, n256d, n512, n768, n1024, G;
-  size_t e256a, e256b, e256c, e128, e32a, e32b, e32c, e4;
+  size_t dxa, n256c, n256d, G;
+  size_t e256a, e4;
   size_t dmod[3], b256a, b256b, b256c, b256d, b512, b2048, b8, bhid;
   size_t wt;   // transposed weight block of the dX GEMM in flight (<= 1536 x 256 elements, fp32 or split bf16: 6 bytes each)
+  size_t pool, pool_bytes;   // single-use buffers: everything a weight-gradient launch on the side stream reads
   size_t total;
 };
+// Bytes of the single-use pool: one buffer per use of every tensor that a weight-gradient launch reads (heads,
+// per attention layer, per E(3) layer, embeddings), each rounded like `take` below.
+static size_t bwd_pool_bytes(int64_t N, int64_t E) {
+  const int64_t dit[] = {N * 256, N * 1024, N * 256, N * 768};
+  const int64_t e3[] = {N * 256, N * 256, E * 128, E * 256, E * 256, E * 32, E * 32, E * 32, N * 512};
+  const int64_t once[] = {N * 512, N * 256, N * 256};
+  size_t tot = 0;
+  auto add = [&](int64_t nfloats) { tot += align_up((size_t)nfloats * 4 + 16, 256); };
+  for (int l = 0; l < 3; ++l) {
+    for (int64_t n : dit) add(n);
+    for (int64_t n : e3) add(n);
+  }
+  for (int64_t n : once) add(n);
+  return tot;
+}
 static void bwd_layout(BwdLayout* L, int64_t N, int64_t E, int32_t B) {
   size_t off = 0;
   auto take = [&](size_t nfloats) { size_t o = off; off += align_up(nfloats * 4 + 16, 256); return o; };
-  L->dxa = take(N * 256); L->n256b = take(N * 256); L->n256c = take(N * 256); L->n256d = take(N * 256);
-  L->n512 = take(N * 512); L->n768 = take(N * 768); L->n1024 = take(N * 1024); L->G = take(N * 3);
-  L->e256a = take(E * 256); L->e256b = take(E * 256); L->e256c = take(E * 256); L->e128 = take(E * 128);
-  L->e32a = take(E * 32); L->e32b = take(E * 32); L->e32c = take(E * 32); L->e4 = take(E * 4);
+  L->dxa = take(N * 256); L->n256c = take(N * 256); L->n256d = take(N * 256); L->G = take(N * 3);
+  L->e256a = take(E * 256); L->e4 = take(E * 4);
   for (int l = 0; l < 3; ++l) L->dmod[l] = take((size_t)B * 1536);
   L->b256a = take((size_t)B * 256); L->b256b = take((size_t)B * 256); L->b256c = take((size_t)B * 256);
   L->b256d = take((size_t)B * 256); L->b512 = take((size_t)B * 512); L->b2048 = take((size_t)B * 2048);
   L->b8 = take((size_t)B * 8); L->bhid = take((size_t)B * 512);
   L->wt = take(1536 * 256 * 3 / 2);
+  L->pool = off;
+  L->pool_bytes = bwd_pool_bytes(N, E);
+  off += L->pool_bytes;
   L->total = off;
 }
 
@@ -53,6 +70,56 @@ __global__ __launch_bounds__(256) void k_transpose_block(const float* __restrict
   for (int i = ty; i < 32; i += 8)
     if (c0 + i < cols && r0 + tx < rows) dst[(size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
+
+// Weight-gradient launches (dW = dY^T X, bias sums, the narrow direct forms) are leaves of the backward sweep: nothing
+// in it reads their results.  They run on a second stream of the calling thread, so that they fill the compute units
+// the input-gradient chain leaves idle (its GEMMs are single rounds of ceil(rows / 128) workgroups: 147 of 256
+// compute units at 18 756 atoms).  Ordering: a side launch is preceded by fork() (the side stream waits for
+// everything enqueued on the caller's stream so far, i.e. for the producer of its dY operand); every tensor a side
+// launch reads lives in a single-use buffer of the workspace pool or in the forward workspace, so the main chain
+// never overwrites it; join() at the end makes the caller's stream wait for the side stream.
+// LIGDIFF_DW_SIDE=0 keeps everything on the caller's stream (A/B switch).
+struct SideStream {
+  hipStream_t s = nullptr, s2 = nullptr;
+  hipEvent_t* ev = nullptr;
+  int next = 0;
+  bool ok = true;
+  static constexpr int N_EV = 32;
+  struct PerDevice { hipStream_t s2 = nullptr; hipEvent_t ev[N_EV + 1] = {}; bool ready = false; };
+  void init(hipStream_t main_stream) {
+    s = s2 = main_stream;
+    static const bool enabled = [] { const char* e = getenv("LIGDIFF_DW_SIDE"); return !(e != nullptr && e[0] == '0'); }();
+    if (!enabled) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (main_stream != nullptr && (hipStreamIsCapturing(main_stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone))
+      return;   // under capture: one stream
+    static thread_local PerDevice dev_ctx[64];
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    PerDevice& d = dev_ctx[dev];
+    if (!d.ready) {   // created once per thread and device, kept until the process ends
+      if (hipStreamCreateWithFlags(&d.s2, hipStreamNonBlocking) != hipSuccess) { d.s2 = nullptr; return; }
+      for (int i = 0; i <= N_EV; ++i)
+        if (hipEventCreateWithFlags(&d.ev[i], hipEventDisableTiming) != hipSuccess) { d.s2 = nullptr; return; }
+      d.ready = true;
+    }
+    if (d.s2 == nullptr) return;
+    s2 = d.s2; ev = d.ev;
+  }
+  bool split() const { return s2 != s; }
+  // the side stream waits for what the caller's stream holds so far; returns the stream for the leaf launches
+  hipStream_t fork() {
+    if (!split()) return s;
+    hipEvent_t e = ev[next];
+    next = (next + 1) % N_EV;
+    if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(s2, e, 0) != hipSuccess) ok = false;
+    return s2;
+  }
+  void join() {
+    if (!split()) return;
+    if (hipEventRecord(ev[N_EV], s2) != hipSuccess || hipStreamWaitEvent(s, ev[N_EV], 0) != hipSuccess) ok = false;
+  }
+};
 
 // Scratch for the transposed weight block (set per ligdiff_backward call from its workspace).
 static thread_local float* g_wt_scratch = nullptr;
@@ -222,20 +289,42 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
   const int nb4N = ceil_div(N, 4), nb4B = ceil_div(B, 4);
   float* dxa = T(L.dxa);
   g_wt_scratch = T(L.wt);
+  SideStream side;
+  side.init(s);
+  struct JoinAtExit {   // also on the error returns below: nothing stays behind on the side stream unobserved
+    SideStream& st;
+    ~JoinAtExit() { st.join(); }
+  } join_at_exit{side};
+  size_t pool_used = 0;
+  bool pool_ok = true;
+  // a buffer nobody writes again in this call once its producer ran (see SideStream)
+  auto fresh = [&](int64_t nfloats) {
+    const size_t need = align_up((size_t)nfloats * 4 + 16, 256);
+    if (pool_used + need > L.pool_bytes) { pool_ok = false; return T(L.pool); }
+    float* p = T(L.pool + pool_used);
+    pool_used += need;
+    return p;
+  };
 
   // ------------------------------------------------------------------ heads (model1.py:741-746)
   const float* x_last = A(F.x2[2]);
-  float* dyh = T(L.n512);
+  float* dyh = fresh((int64_t)N * 512);
   gemm_dx<8, MUL_NONE, false>(d_atom, LD_A, N, LD_A, w[W_HEAD(0, HEAD_W3)], 256, 256, dyh, 512, nullptr, 0, s);
   hipLaunchKernelGGL(k_small_dx<3>, dim3(nb4N), dim3(256), 0, s, d_pos, w[W_HEAD(1, HEAD_W3)], dyh, 512, 256, N);
-  gemm_dw_direct(d_atom, LD_A, LD_A, A(F.yh), 512, 256, N, gr[W_HEAD(0, HEAD_W3)], 256, s, gr[W_HEAD(0, HEAD_B3)]);
-  hipLaunchKernelGGL(k_small_dw<3>, dim3(ceil_div(N, 128)), dim3(256), 0, s, d_pos, A(F.yh), 512, 256,
-                     gr[W_HEAD(1, HEAD_W3)], gr[W_HEAD(1, HEAD_B3)], N);
-  for (int h = 0; h < 2; ++h) {
+  {
+    hipStream_t sd = side.fork();   // (reads the caller's d_atom / d_pos and the forward workspace only)
+    gemm_dw_direct(d_atom, LD_A, LD_A, A(F.yh), 512, 256, N, gr[W_HEAD(0, HEAD_W3)], 256, sd, gr[W_HEAD(0, HEAD_B3)]);
+    hipLaunchKernelGGL(k_small_dw<3>, dim3(ceil_div(N, 128)), dim3(256), 0, sd, d_pos, A(F.yh), 512, 256,
+                       gr[W_HEAD(1, HEAD_W3)], gr[W_HEAD(1, HEAD_B3)], N);
+  }
+  for (int h = 0; h < 2; ++h)
     ln_bwd<1, 0>(A(F.u_head) + h * 256, 512, w[W_HEAD(h, HEAD_G)], w[W_HEAD(h, HEAD_BE)], 1e-5f, dyh + h * 256, 512,
                  nullptr, 0, nullptr, dyh + h * 256, 512, gr[W_HEAD(h, HEAD_G)], gr[W_HEAD(h, HEAD_BE)], N, s);
-    if (!gemm_dw<8>(dyh + h * 256, 512, 256, x_last, 256, 256, N, gr[W_HEAD(h, HEAD_W0)], 256, s, gr[W_HEAD(h, HEAD_B0)]))
-      colsum(dyh + h * 256, 512, N, 256, nullptr, gr[W_HEAD(h, HEAD_B0)], s);
+  {
+    hipStream_t sd = side.fork();
+    for (int h = 0; h < 2; ++h)
+      if (!gemm_dw<8>(dyh + h * 256, 512, 256, x_last, 256, 256, N, gr[W_HEAD(h, HEAD_W0)], 256, sd, gr[W_HEAD(h, HEAD_B0)]))
+        colsum(dyh + h * 256, 512, N, 256, nullptr, gr[W_HEAD(h, HEAD_B0)], sd);
   }
   gemm_dx<8, MUL_NONE, false>(dyh, 512, N, 256, w[W_HEAD(0, HEAD_W0)], 256, 256, dxa, 256, nullptr, 0, s);
   gemm_dx<8, MUL_NONE, true>(dyh + 256, 512, N, 256, w[W_HEAD(1, HEAD_W0)], 256, 256, dxa, 256, nullptr, 0, s);
@@ -261,7 +350,7 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
     const float* x_in = (l == 0) ? A(F.h_e3[2]) : A(F.x2[l - 1]);
     const float* mod = A(F.mod[l]);
     float* dmod = T(L.dmod[l]);
-    float* t256b = T(L.n256b);
+    float* t256b = fresh((int64_t)N * 256);
     float* t256c = T(L.n256c);
     DropSite d_att, d_hid, d_out;
     if (!make_drop_site(dropout, l, LIGDIFF_DROP_ATTENTION, &d_att) || !make_drop_site(dropout, l, LIGDIFF_DROP_FFN_HIDDEN, &d_hid) ||
@@ -270,23 +359,33 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
     // x2 = x1 + gate_mlp * Dropout(ffh W3^T + b)   (fproj holds the masked projection)
     hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dxa, A(F.fproj[l]), mod, 1536, 1280, g->mol_ptr, B, t256b, dmod,
                        d_out);
-    if (!gemm_dw<8>(t256b, 256, 256, A(F.ffh[l]), 1024, 1024, N, gr[W_DIT(l, DIT_FF3_W)], 1024, s, gr[W_DIT(l, DIT_FF3_B)]))
-      colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_FF3_B)], s);
-    float* dffh = T(L.n1024);
+    {
+      hipStream_t sd = side.fork();
+      if (!gemm_dw<8>(t256b, 256, 256, A(F.ffh[l]), 1024, 1024, N, gr[W_DIT(l, DIT_FF3_W)], 1024, sd, gr[W_DIT(l, DIT_FF3_B)]))
+        colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_FF3_B)], sd);
+    }
+    float* dffh = fresh((int64_t)N * 1024);
     gemm_dx<8, MUL_GELU_GRAD, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1024, dffh, 1024,
                                      A(F.ffh_pre[l]), 1024, s, &d_hid);   // ffh = Dropout(GELU(pre))
-    if (!gemm_dw<8>(dffh, 1024, 1024, A(F.xn2[l]), 256, 256, N, gr[W_DIT(l, DIT_FF0_W)], 256, s, gr[W_DIT(l, DIT_FF0_B)]))
-      colsum(dffh, 1024, N, 1024, nullptr, gr[W_DIT(l, DIT_FF0_B)], s);
+    {
+      hipStream_t sd = side.fork();
+      if (!gemm_dw<8>(dffh, 1024, 1024, A(F.xn2[l]), 256, 256, N, gr[W_DIT(l, DIT_FF0_W)], 256, sd, gr[W_DIT(l, DIT_FF0_B)]))
+        colsum(dffh, 1024, N, 1024, nullptr, gr[W_DIT(l, DIT_FF0_B)], sd);
+    }
     gemm_dx<8, MUL_NONE, false>(dffh, 1024, N, 1024, w[W_DIT(l, DIT_FF0_W)], 256, 256, t256c, 256, nullptr, 0, s);
     hipLaunchKernelGGL(k_lnmod_bwd, dim3(B), dim3(256), 0, s, A(F.x1[l]), t256c, dxa, mod, 1536, 768, 1024,
                        g->mol_ptr, B, dxa, dmod);
     // x1 = x_in + gate_msa * (att Wo^T + b)
+    t256b = fresh((int64_t)N * 256);
     hipLaunchKernelGGL(k_gate_bwd, dim3(B), dim3(256), 0, s, dxa, A(F.oproj[l]), mod, 1536, 512, g->mol_ptr, B, t256b, dmod,
                        DropSite{});
-    if (!gemm_dw<8>(t256b, 256, 256, A(F.att[l]), 256, 256, N, gr[W_DIT(l, DIT_OUT_W)], 256, s, gr[W_DIT(l, DIT_OUT_B)]))
-      colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_OUT_B)], s);
+    {
+      hipStream_t sd = side.fork();
+      if (!gemm_dw<8>(t256b, 256, 256, A(F.att[l]), 256, 256, N, gr[W_DIT(l, DIT_OUT_W)], 256, sd, gr[W_DIT(l, DIT_OUT_B)]))
+        colsum(t256b, 256, N, 256, nullptr, gr[W_DIT(l, DIT_OUT_B)], sd);
+    }
     gemm_dx<8, MUL_NONE, false>(t256b, 256, N, 256, w[W_DIT(l, DIT_OUT_W)], 256, 256, t256c, 256, nullptr, 0, s);
-    float* dqkv = T(L.n768);
+    float* dqkv = fresh((int64_t)N * 768);
     if (d_att.thr != 0u) {   // probabilities were dropout-masked in the forward pass
       const int tk = (g->max_mol_atoms + 31) / 32;
       const float* qkv_l = A(F.qkv[l]);
@@ -329,8 +428,11 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
         hipLaunchKernelGGL((k_attention_bwd_mfma<4, 2>), dim3(ceil_div((long)B * 8, 2)), dim3(128), 2 * 128 * 134 * 4, s, qkv_l,
                            att_l, t256c, lse_l, g->mol_ptr, dqkv, B);
     }
-    if (!gemm_dw<8>(dqkv, 768, 768, A(F.xn1[l]), 256, 256, N, gr[W_DIT(l, DIT_INP_W)], 256, s, gr[W_DIT(l, DIT_INP_B)]))
-      colsum(dqkv, 768, N, 768, nullptr, gr[W_DIT(l, DIT_INP_B)], s);
+    {
+      hipStream_t sd = side.fork();
+      if (!gemm_dw<8>(dqkv, 768, 768, A(F.xn1[l]), 256, 256, N, gr[W_DIT(l, DIT_INP_W)], 256, sd, gr[W_DIT(l, DIT_INP_B)]))
+        colsum(dqkv, 768, N, 768, nullptr, gr[W_DIT(l, DIT_INP_B)], sd);
+    }
     gemm_dx<8, MUL_NONE, false>(dqkv, 768, N, 768, w[W_DIT(l, DIT_INP_W)], 256, 256, t256c, 256, nullptr, 0, s);
     hipLaunchKernelGGL(k_lnmod_bwd, dim3(B), dim3(256), 0, s, x_in, t256c, dxa, mod, 1536, 0, 256, g->mol_ptr, B,
                        dxa, dmod);
@@ -341,58 +443,76 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
     const float* h_in = (l == 0) ? A(F.h0) : A(F.h_e3[l - 1]);
     const float* W1 = w[W_E3(l, E3_EN0_W)];
     float* dW1 = gr[W_E3(l, E3_EN0_W)];
-    float* t256b = T(L.n256b);
-    float* t256c = T(L.n256c);
+    float* t256b = fresh((int64_t)N * 256);
+    float* t256c = fresh((int64_t)N * 256);
     float* dagg = T(L.n256d);
     // h_out = h_in + LN(hid Wn2^T + b)
     ln_bwd<0, 0>(A(F.u_h[l]), 256, w[W_E3(l, E3_NN3_G)], w[W_E3(l, E3_NN3_B)], 1e-5f, dxa, 256, nullptr, 0, nullptr,
                  t256b, 256, gr[W_E3(l, E3_NN3_G)], gr[W_E3(l, E3_NN3_B)], N, s);
-    if (!gemm_dw<8>(t256b, 256, 256, A(F.hid[l]), 256, 256, N, gr[W_E3(l, E3_NN2_W)], 256, s, gr[W_E3(l, E3_NN2_B)]))
-      colsum(t256b, 256, N, 256, nullptr, gr[W_E3(l, E3_NN2_B)], s);
+    {
+      hipStream_t sd = side.fork();
+      if (!gemm_dw<8>(t256b, 256, 256, A(F.hid[l]), 256, 256, N, gr[W_E3(l, E3_NN2_W)], 256, sd, gr[W_E3(l, E3_NN2_B)]))
+        colsum(t256b, 256, N, 256, nullptr, gr[W_E3(l, E3_NN2_B)], sd);
+    }
     gemm_dx<8, MUL_SILU_GRAD, false>(t256b, 256, N, 256, w[W_E3(l, E3_NN2_W)], 256, 256, t256c, 256, A(F.hid_pre[l]),
                                      256, s);
-    gemm_dw<8>(t256c, 256, 256, h_in, 256, 256, N, gr[W_E3(l, E3_NN0_W)], 512, s);
-    if (!gemm_dw<8>(t256c, 256, 256, A(F.agg[l]), 256, 256, N, gr[W_E3(l, E3_NN0_W)] + 256, 512, s, gr[W_E3(l, E3_NN0_B)]))
-      colsum(t256c, 256, N, 256, nullptr, gr[W_E3(l, E3_NN0_B)], s);
+    {
+      hipStream_t sd = side.fork();
+      gemm_dw<8>(t256c, 256, 256, h_in, 256, 256, N, gr[W_E3(l, E3_NN0_W)], 512, sd);
+      if (!gemm_dw<8>(t256c, 256, 256, A(F.agg[l]), 256, 256, N, gr[W_E3(l, E3_NN0_W)] + 256, 512, sd, gr[W_E3(l, E3_NN0_B)]))
+        colsum(t256c, 256, N, 256, nullptr, gr[W_E3(l, E3_NN0_B)], sd);
+    }
     gemm_dx<8, MUL_NONE, true>(t256c, 256, N, 256, w[W_E3(l, E3_NN0_W)], 512, 256, dxa, 256, nullptr, 0, s);
     gemm_dx<8, MUL_NONE, false>(t256c, 256, N, 256, w[W_E3(l, E3_NN0_W)] + 256, 512, 256, dagg, 256, nullptr, 0, s);
     if (E > 0) {
       float* drel = T(L.e4);
-      float* dhc = T(L.e128);
+      float* dhc = fresh((int64_t)E * 128);
       float* e256a = T(L.e256a);
-      float* e256b = T(L.e256b);
-      float* dpre = T(L.e256c);
+      float* e256b = fresh((int64_t)E * 256);
+      float* dpre = fresh((int64_t)E * 256);
       // coordinate gate
       hipLaunchKernelGGL(k_coord_bwd, dim3(512), dim3(256), 0, s, G, g->src, g->dst, A(F.rel[l]), A(F.cw[l]),
                          A(F.hc_pre[l]), w[W_E3(l, E3_CN2_W)], drel, dhc, gr[W_E3(l, E3_CN2_W)], gr[W_E3(l, E3_CN2_B)], E);
-      if (!gemm_dw<8>(dhc, 128, 128, A(F.msg[l]), 256, 256, E, gr[W_E3(l, E3_CN0_W)], 256, s, gr[W_E3(l, E3_CN0_B)]))
-        colsum(dhc, 128, E, 128, nullptr, gr[W_E3(l, E3_CN0_B)], s);
+      {
+        hipStream_t sd = side.fork();
+        if (!gemm_dw<8>(dhc, 128, 128, A(F.msg[l]), 256, 256, E, gr[W_E3(l, E3_CN0_W)], 256, sd, gr[W_E3(l, E3_CN0_B)]))
+          colsum(dhc, 128, E, 128, nullptr, gr[W_E3(l, E3_CN0_B)], sd);
+      }
       gemm_dx<8, MUL_NONE, false>(dhc, 128, E, 128, w[W_E3(l, E3_CN0_W)], 256, 256, e256a, 256, nullptr, 0, s);
       // msg = LN(a1 W2^T + b); its gradient = coordinate branch + aggregated branch (dagg[dst])
       ln_bwd<0, 0>(A(F.u_m[l]), 256, w[W_E3(l, E3_EN3_G)], w[W_E3(l, E3_EN3_B)], 1e-5f, e256a, 256, dagg, 256, g->dst,
                    e256b, 256, gr[W_E3(l, E3_EN3_G)], gr[W_E3(l, E3_EN3_B)], E, s);
-      if (!gemm_dw<8>(e256b, 256, 256, A(F.a1[l]), 256, 256, E, gr[W_E3(l, E3_EN2_W)], 256, s, gr[W_E3(l, E3_EN2_B)]))
-        colsum(e256b, 256, E, 256, nullptr, gr[W_E3(l, E3_EN2_B)], s);
+      {
+        hipStream_t sd = side.fork();
+        if (!gemm_dw<8>(e256b, 256, 256, A(F.a1[l]), 256, 256, E, gr[W_E3(l, E3_EN2_W)], 256, sd, gr[W_E3(l, E3_EN2_B)]))
+          colsum(e256b, 256, E, 256, nullptr, gr[W_E3(l, E3_EN2_B)], sd);
+      }
       gemm_dx<8, MUL_SILU_GRAD, false>(e256b, 256, E, 256, w[W_E3(l, E3_EN2_W)], 256, 256, dpre, 256, A(F.pre_e[l]),
                                        256, s);
       // pre = Pa[src] + Pb[dst] + Wc rbf + b1.  The bias gradient sum_e dpre[e] equals the column sum of
       // the per-destination gather dP[:, 256:512] (every edge has exactly one destination atom), which
       // the weight-gradient GEMM on that block produces in the same pass (N rows instead of E).
-      gemm_dw_direct(dpre, 256, 256, A(F.rbf[l]), 32, 32, E, dW1 + 512, 544, s);
-      float* drbf = T(L.e32a);
+      gemm_dw_direct(dpre, 256, 256, A(F.rbf[l]), 32, 32, E, dW1 + 512, 544, side.fork());
+      float* drbf = fresh((int64_t)E * 32);
       gemm_dx<4, MUL_NONE, false>(dpre, 256, E, 256, W1 + 512, 544, 32, drbf, 32, nullptr, 0, s);
-      float* dr1pre = T(L.e32b);
-      float* r1 = T(L.e32c);
+      float* dr1pre = fresh((int64_t)E * 32);
+      float* r1 = fresh((int64_t)E * 32);
       hipLaunchKernelGGL(k_radial_bwd, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, A(F.r1pre[l]), A(F.dist[l]),
                          A(F.rel[l]), w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB2_W)], drel, dr1pre, r1, E);
-      gemm_dw_direct(drbf, 32, 32, r1, 32, 32, E, gr[W_E3(l, E3_RB2_W)], 32, s);
-      hipLaunchKernelGGL(k_radial_colsums, dim3(ceil_div(E, 256)), dim3(256), 0, s, drbf, dr1pre, A(F.dist[l]),
-                         gr[W_E3(l, E3_RB2_B)], gr[W_E3(l, E3_RB0_W)], gr[W_E3(l, E3_RB0_B)], E);
-      float* dP = T(L.n512);
+      {
+        hipStream_t sd = side.fork();
+        gemm_dw_direct(drbf, 32, 32, r1, 32, 32, E, gr[W_E3(l, E3_RB2_W)], 32, sd);
+        hipLaunchKernelGGL(k_radial_colsums, dim3(ceil_div(E, 256)), dim3(256), 0, sd, drbf, dr1pre, A(F.dist[l]),
+                           gr[W_E3(l, E3_RB2_B)], gr[W_E3(l, E3_RB0_W)], gr[W_E3(l, E3_RB0_B)], E);
+      }
+      float* dP = fresh((int64_t)N * 512);
       hipLaunchKernelGGL(k_dp_gather, dim3(nb4N), dim3(256), 0, s, dpre, g->dst_ptr, g->src_ptr, g->src_slot, dP, N);
-      gemm_dw<8>(dP, 512, 256, h_in, 256, 256, N, dW1, 544, s);
-      if (!gemm_dw<8>(dP + 256, 512, 256, h_in, 256, 256, N, dW1 + 256, 544, s, gr[W_E3(l, E3_EN0_B)]))
-        colsum(dpre, 256, E, 256, nullptr, gr[W_E3(l, E3_EN0_B)], s);
+      {
+        hipStream_t sd = side.fork();
+        gemm_dw<8>(dP, 512, 256, h_in, 256, 256, N, dW1, 544, sd);
+        if (!gemm_dw<8>(dP + 256, 512, 256, h_in, 256, 256, N, dW1 + 256, 544, sd, gr[W_E3(l, E3_EN0_B)]))
+          colsum(dpre, 256, E, 256, nullptr, gr[W_E3(l, E3_EN0_B)], sd);
+      }
       gemm_dx<8, MUL_NONE, true>(dP, 512, N, 256, W1, 544, 256, dxa, 256, nullptr, 0, s);
       gemm_dx<8, MUL_NONE, true>(dP + 256, 512, N, 256, W1 + 256, 544, 256, dxa, 256, nullptr, 0, s);
       if (l > 0)  // layer 0 reads the data coordinates: no parameter lies upstream of them
@@ -402,17 +522,20 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
 
   // ------------------------------------------------------------------ embeddings (model1.py:709-718)
   {
-    float* du = T(L.n256b);
+    float* du = fresh((int64_t)N * 256);
     ln_bwd<0, 1>(A(F.ua), 256, w[W_ATOM_G], w[W_ATOM_BE], 1e-5f, dxa, 256, nullptr, 0, nullptr, du, 256, gr[W_ATOM_G],
                  gr[W_ATOM_BE], N, s);
-    gemm_dw_direct(du, 256, 256, x, LD_A, LD_A, N, gr[W_ATOM_W], LD_A, s, gr[W_ATOM_B]);
+    gemm_dw_direct(du, 256, 256, x, LD_A, LD_A, N, gr[W_ATOM_W], LD_A, side.fork(), gr[W_ATOM_B]);
     float* up = T(L.n256c);
-    float* dup = T(L.n256d);
+    float* dup = fresh((int64_t)N * 256);
     hipLaunchKernelGGL(k_pos_embed_pre, dim3(nb4N), dim3(256), 0, s, pos, w[W_POS_W], w[W_POS_B], up, N);
     ln_bwd<0, 1>(up, 256, w[W_POS_G], w[W_POS_BE], 1e-5f, dxa, 256, nullptr, 0, nullptr, dup, 256, gr[W_POS_G],
                  gr[W_POS_BE], N, s);
-    hipLaunchKernelGGL(k_pos_embed_dw, dim3(ceil_div(N, 128)), dim3(256), 0, s, dup, pos, gr[W_POS_W], N);
-    colsum(dup, 256, N, 256, nullptr, gr[W_POS_B], s);
+    {
+      hipStream_t sd = side.fork();
+      hipLaunchKernelGGL(k_pos_embed_dw, dim3(ceil_div(N, 128)), dim3(256), 0, sd, dup, pos, gr[W_POS_W], N);
+      colsum(dup, 256, N, 256, nullptr, gr[W_POS_B], sd);
+    }
   }
   float* dmolsum = T(L.b256a);  // sum over each molecule's atoms of dh0: gradient of t_emb[mol] and prop_emb[mol]
   hipLaunchKernelGGL(k_mol_sum, dim3(nb4B), dim3(256), 0, s, dxa, g->mol_ptr, B, dmolsum);
@@ -465,7 +588,10 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
     if (!gemm_dw<8>(dt1, 512, 512, A(F.tf), 256, 256, B, gr[W_T0_W], 256, s, gr[W_T0_B]))
       colsum(dt1, 512, B, 512, nullptr, gr[W_T0_B], s);
   }
+  side.join();   // the caller's stream now also waits for every weight-gradient launch (and once more at scope exit)
   LD_CHECK_LAUNCH();
+  if (!side.ok) return LIGDIFF_ERR_LAUNCH;
+  if (!pool_ok) return LIGDIFF_ERR_WORKSPACE;   // (cannot happen while bwd_pool_bytes lists every fresh() above)
   return LIGDIFF_OK;
 }
 

@@ -179,6 +179,17 @@ extern "C" int ligdiff_set_split_gemm(int enabled) {
   g_split_mode.store(enabled ? 1 : 0, std::memory_order_relaxed);
   return m;
 }
+extern "C" void ligdiff_default_options(ligdiff_options* o) {
+  if (o == nullptr) return;
+  ligdiff_options_init(o);
+  const ligdiff_options* saved = t_options;
+  t_options = nullptr;   // the process-wide defaults, not the calling thread's current call
+  o->gemm_mode = split_gemm_enabled() ? 1 : 0;
+  o->chain_mode = chain_mode();
+  o->concurrent_calls = chain_concurrent_calls();
+  o->cfg_two_pass = cfg_one_pass() ? 0 : 1;
+  t_options = saved;
+}
 FwdPlan forward_plan(int64_t N, int64_t E, int64_t B, int max_mol_atoms) {
   const ligdiff_options* o = t_options;
   auto pick = [](int field, bool by_rule) { return field >= 0 ? field != 0 : by_rule; };

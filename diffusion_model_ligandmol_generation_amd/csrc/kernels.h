@@ -517,21 +517,25 @@ __global__ __launch_bounds__(256) void k_attention_reg(const float* __restrict__
       q[c * 4 + 0] = v[0] * scale; q[c * 4 + 1] = v[1] * scale; q[c * 4 + 2] = v[2] * scale; q[c * 4 + 3] = v[3] * scale;
     }
   }
+  // key tiles beyond the molecule (t * 32 >= n, the same for every lane of the wave) are skipped: their scores
+  // are masked to -inf below and their probabilities are exactly 0
   f32x16 sc[TK];
 #pragma unroll
   for (int t = 0; t < TK; ++t) {
-    const int kr = t * 32 + fi;
-    const float* kp = base + (size_t)(kr < n ? kr : n - 1) * 768 + 256 + 16 * h;
-    f32x4 kf[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const f32x4*>(kp + c * 4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+    if (t * 32 < n) {
+      const int kr = t * 32 + fi;
+      const float* kp = base + (size_t)(kr < n ? kr : n - 1) * 768 + 256 + 16 * h;
+      f32x4 kf[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const f32x4*>(kp + c * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)   // A = K[t*32 + fi, 16h + 4c + e], B = scale Q[qi, same d]
-        sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c][e], q[c * 4 + e], sc[t], 0, 0, 0);
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)   // A = K[t*32 + fi, 16h + 4c + e], B = scale Q[qi, same d]
+          sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c][e], q[c * 4 + e], sc[t], 0, 0, 0);
+    }
   }
   float vf[TK][16];   // V[j(r, h), d = fi], fetched while the softmax runs
 #pragma unroll
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(256) void k_attention_reg(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int vr = t * 32 + G_ROW_ATT(r, h);
-      vf[t][r] = base[(size_t)(vr < n ? vr : n - 1) * 768 + 512 + fi];
+      vf[t][r] = t * 32 < n ? base[(size_t)(vr < n ? vr : n - 1) * 768 + 512 + fi] : 0.f;
     }
   float m = -INFINITY;
 #pragma unroll
@@ -576,8 +580,10 @@ __global__ __launch_bounds__(256) void k_attention_reg(const float* __restrict__
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
   for (int t = 0; t < TK; ++t)
+    if (t * 32 < n) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t][r], sc[t][r], o, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t][r], sc[t][r], o, 0, 0, 0);
+    }
   if (qi < n) {
     const float inv = 1.0f / l;
     float* op = out + (size_t)(a0 + qi) * 256 + head * 32;

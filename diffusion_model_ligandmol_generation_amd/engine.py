@@ -142,6 +142,12 @@ class ScoreNetworkEngine:
         node_chain, mol_wave, edge_reduce, cfg_two_pass); everything else stays "not set"."""
         return Options(**fields)
 
+    def default_options(self):
+        """What a library call without options currently uses (process-wide setters / environment); read-only."""
+        out = Options()
+        self.lib.ligdiff_default_options(C.byref(out))
+        return out
+
     def plan(self, n_atoms, n_edges, n_mols, max_mol_atoms, options=None):
         """ligdiff_plan: the kernel forms the library would pick for ONE call over a request of these sizes,
         as an Options struct to pass to every call that processes a part of the request (halves on two

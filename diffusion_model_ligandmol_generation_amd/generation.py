@@ -36,7 +36,10 @@ class ResearchValidatedGenerator:
         self.model = model
         self.use_ema = use_ema
         self.device = next(model.parameters()).device
-        self.batch_atoms = 32768          # atoms per packed sampling batch
+        self.batch_atoms = 32768          # atoms per packed sampling batch (256 row blocks of 128: one round of the fused kernels)
+        # ... and in split-operand mode, whose separate launches have no such round and gain from longer grids
+        # (29-atom ligands: 510 molecules/s at 1024 per batch, 562 at 2048, 570 at 4096)
+        self.batch_atoms_split = 131072
         self.batch_edges = 4 << 20        # directed edges per packed sampling batch (fully connected molecules)
         # A DDPM batch of at least this many atoms runs as TWO concurrent halves (two host threads, two streams):
         # molecules are independent and the Gaussian draws are keyed by the global atom index, so the result is
@@ -88,6 +91,10 @@ class ResearchValidatedGenerator:
         self.seed = seed + 1
         return seed
 
+    def _default_split(self):
+        """The library's process-wide GEMM mode."""
+        return bool(self.model.engine().default_options().gemm_mode)
+
     def _edge_count(self, n, connectivity):
         if connectivity == "full":
             return n * (n - 1)
@@ -105,12 +112,15 @@ class ResearchValidatedGenerator:
         seed = self._next_seed() if seed is None else seed
         results, flags = [], []
         i = 0
+        o = options if options is not None else self.options
+        split = bool(o.gemm_mode) if (o is not None and o.gemm_mode >= 0) else self._default_split()
+        batch_atoms = self.batch_atoms_split if split else self.batch_atoms
         with torch.no_grad():
             while i < len(sizes):
                 j, tot, etot = i, 0, 0
                 while j < len(sizes):
                     e_j = self._edge_count(sizes[j], connectivity)
-                    if j > i and (tot + sizes[j] > self.batch_atoms or etot + e_j > self.batch_edges):
+                    if j > i and (tot + sizes[j] > batch_atoms or etot + e_j > self.batch_edges):
                         break
                     tot += sizes[j]
                     etot += e_j
@@ -206,11 +216,17 @@ class ResearchValidatedGenerator:
             raise ValueError("connectivity must be 'template', 'full', an edge_index tensor or a PackedGraph")
         N, B = graph.n_atoms, graph.n_mols
         props = self._prepare_pilot_properties(target_properties)
+        # dict-valued properties (generation.py:510-512 passes them on; the scenarios of generation.py:689-757 are
+        # dicts): the reference's model call fails on them and returns all-zero predictions (model1.py:337, :757-764),
+        # so the conditional prediction of every step is zero.  Reproduced as that, through the host-driven loop.
+        zero_cond = props is not None and not torch.is_tensor(props)
+        if zero_cond:
+            props = None
         if props is not None:
             props = props.to(dev).float()
             if props.shape[0] == 1 and B > 1:
                 props = props.repeat(B, 1)
-        guided = props is not None and guidance_scale > 1.0                     # generation.py:428
+        guided = (props is not None or zero_cond) and guidance_scale > 1.0      # generation.py:428
         T = model.timesteps
         init_step = 0xFFFFFFFF
         if noise is None:
@@ -220,13 +236,13 @@ class ResearchValidatedGenerator:
             x = (noise("x0", T, (N, 119)) * temperature).contiguous()
             pos = (noise("pos0", T, (N, 3)) * temperature).contiguous()
         rejected = torch.zeros(B, dtype=torch.int32, device=dev)
-        halves = (not use_ddim and noise is None and trace is None and use_graph and self.concurrent_atoms is not None
+        halves = (not zero_cond and not use_ddim and noise is None and trace is None and use_graph and self.concurrent_atoms is not None
                   and N >= self.concurrent_atoms and B >= 8 and connectivity in ("template", "full"))
         # kernel forms of this batch, fixed on the whole batch's sizes whichever way it is then cut
         opts = eng.plan_graph(graph, options if options is not None else self.options)
         if halves:   # the hint only steers choices between bit-identical GEMM tile forms once the plan is fixed
             opts = opts.copy(concurrent_calls=2)
-        if not use_ddim and noise is None and trace is None:
+        if not use_ddim and noise is None and trace is None and not zero_cond:
             if halves:
                 self._ddpm_two_halves(sizes, connectivity, x, pos, props, guidance_scale, temperature, T, seed, atom_offset,
                                       opts)
@@ -237,7 +253,7 @@ class ResearchValidatedGenerator:
         t_index = torch.zeros(1, dtype=torch.int32, device=dev)
         if use_ddim:
             steps = torch.linspace(T - 1, 0, num_steps, dtype=torch.long).tolist()  # generation.py:305
-            if noise is None and trace is None:
+            if noise is None and trace is None and not zero_cond:
                 eng.ddim_sample(model, graph, x, pos, steps, rejected, props, guidance_scale, use_graph, options=opts)
                 return x, pos, graph, rejected
         else:
@@ -246,8 +262,11 @@ class ResearchValidatedGenerator:
             if trace is not None:
                 trace(t, x, pos)
             t_index.fill_(t)
-            ex, ep, _ = eng.forward(graph, x, pos, None, props, want_props=False, t_index=t_index, options=opts)
             exu = epu = None
+            if zero_cond:
+                ex, ep = torch.zeros_like(x), torch.zeros_like(pos)
+            else:
+                ex, ep, _ = eng.forward(graph, x, pos, None, props, want_props=False, t_index=t_index, options=opts)
             if guided:
                 exu, epu, _ = eng.forward(graph, x, pos, None, None, want_props=False, t_index=t_index, options=opts)
             nx = npos = None
@@ -315,12 +334,13 @@ class ResearchValidatedGenerator:
         return self._validate_research_compliance(x, pos, num_atoms)
 
     def _prepare_pilot_properties(self, target_properties):
-        """generation.py:496-516; dict-valued properties make the reference's model call
-        fail (model1.py:337) and are rejected here."""
+        """generation.py:496-516: a tensor becomes [1,15] / [B,15] (None if it holds NaN / Inf); anything else -
+        the dict-valued scenarios of generation.py:689-757 - is passed on unchanged, and the samplers then treat the
+        conditional prediction as zero, which is what the reference's failing model call returns (model1.py:757-764)."""
         if target_properties is None:
             return None
         if not torch.is_tensor(target_properties):
-            raise TypeError("target_properties must be a tensor of 15 values (or [B,15]) or None")
+            return target_properties
         if target_properties.dim() == 1:
             target_properties = target_properties.unsqueeze(0)
         if torch.isnan(target_properties).any() or torch.isinf(target_properties).any():

@@ -158,6 +158,10 @@ typedef struct ligdiff_options {
 /* Sets every field of *o to "not set". */
 void ligdiff_options_init(ligdiff_options* o);
 
+/* Fills *o with what a call WITHOUT options would currently use for gemm_mode, chain_mode, concurrent_calls and
+ * cfg_two_pass (the process-wide setters and the environment); the kernel-form fields stay unset.  Read-only. */
+void ligdiff_default_options(ligdiff_options* o);
+
 /* Resolves the kernel-form fields (edge_chain, node_chain, mol_wave, edge_reduce) that `in` (may be NULL)
  * leaves unset into 0 / 1 for a request of these sizes on the current device, as the library would choose
  * for ONE call over the whole request; the other fields are copied.  Pass *out to every call that

@@ -34,6 +34,14 @@ def _predict(sd, x, pos, edge_index, batch, t, props, guidance_scale, max_atoms,
     """generation.py:428-451: classifier-free combination when props given and scale > 1.
     The 'unconditional' branch passes properties=None (no property term at all)."""
     tb = torch.tensor([t])
+    if props is not None and not torch.is_tensor(props):
+        # dict-valued properties (the scenarios of generation.py:689-757 reach the model unchanged, :510-512): the
+        # model's forward fails on them (model1.py:337, no .shape) and returns all-zero predictions (model1.py:757-764)
+        if guidance_scale > 1.0:
+            au, pu, _ = score_network_forward(sd, x, pos, edge_index, batch, tb, None,
+                                              max_atoms=max_atoms, pad_to_max_atoms=pad)
+            return au + guidance_scale * (0.0 - au), pu + guidance_scale * (0.0 - pu)
+        return torch.zeros_like(x), torch.zeros_like(pos)
     if props is not None and guidance_scale > 1.0:
         ac, pc, _ = score_network_forward(sd, x, pos, edge_index, batch, tb, props,
                                           max_atoms=max_atoms, pad_to_max_atoms=pad)
@@ -77,7 +85,7 @@ def ddpm_sample(sd, sched, num_atoms, noise, target_properties=None, guidance_sc
     ei = _edges(num_atoms, edge_index)
     batch = torch.zeros(num_atoms, dtype=torch.long)
     props = target_properties
-    if props is not None and props.dim() == 1:
+    if torch.is_tensor(props) and props.dim() == 1:
         props = props.unsqueeze(0)                                  # generation.py:503-504
     for t in reversed(range(T)):
         if trace is not None:
@@ -107,7 +115,7 @@ def ddim_sample(sd, sched, num_atoms, noise, num_steps, target_properties=None,
     batch = torch.zeros(num_atoms, dtype=torch.long)
     ts = ddim_timesteps(T, num_steps)
     props = target_properties
-    if props is not None and props.dim() == 1:
+    if torch.is_tensor(props) and props.dim() == 1:
         props = props.unsqueeze(0)
     ac = sched["alphas_cumprod"]
     for i, t in enumerate(ts.tolist()):

@@ -7,6 +7,9 @@ the two shapes the reference's own data pipeline produces that the other fixture
    F.mse_loss(prop_pred [B,15], properties [B,14 B]) raises inside the try block of train.py:388-397.
 2. A one-atom molecule with the [[0, 0]] self-loop edge of data_utils.py:893-895, and one with no edge at all,
    next to ordinary molecules: eval forward outputs and the same train-mode loss step.
+3. Dict-valued ``target_properties`` (the scenarios of generation.py:689-757): the model call fails on them and
+   returns zeros (model1.py:337, :757-764); DDPM trajectories of generation.py:393-484 with such properties, with
+   and without guidance.
 Dropout probabilities are 0 as in make_golden.py; the random draws of the loss step are recorded."""
 import contextlib
 import io
@@ -113,6 +116,29 @@ def main():
     out["gradnorm"] = np.float64(gsq ** 0.5)
     out.update(x=xt.numpy(), pos=post.numpy(), edge_index=eit.numpy(), batch=bt.numpy(), props_flat=props_flat.numpy(),
                u=u.numpy(), noise=noise.numpy(), null_rand=null_rand.numpy())
+    # ---- DDPM with dict-valued target properties (seeded draws in the reference's call order)
+    for tag, scale in (("dict_guided", 2.0), ("dict_plain", 1.0)):
+        T, n, seed = 20, 13, 2468
+        smodel = build_model(m1, timesteps=T).eval()
+        with contextlib.redirect_stdout(io.StringIO()):
+            generator = G(smodel)
+        final = {}
+
+        def capture(x_, pos_, n_, _fin=final):
+            _fin["x"], _fin["pos"] = x_.clone(), pos_.clone()
+            return True
+
+        generator._validate_final_molecule = capture
+        tp = {"molecular_weight": 350.0, "logp": 2.5, "qed": 0.8}
+        torch.manual_seed(seed)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), torch.no_grad():
+            res = generator.ddpm_sampling_fixed(n, tp, scale, 0.9)
+        assert res is not None and "Forward pass failed" in buf.getvalue(), buf.getvalue()[:300]
+        out[f"{tag}_meta"] = np.array([T, n, seed])
+        out[f"{tag}_scale"] = np.float32(scale)
+        out[f"{tag}_final_x"] = final["x"].numpy()
+        out[f"{tag}_final_pos"] = final["pos"].numpy()
     np.savez_compressed(os.path.join(HERE, "quirk.npz"), **out)
     print("wrote quirk.npz:", {k: float(v) for k, v in out.items() if k.startswith("loss_") and k != "loss_keys"})
     print("parameters with a gradient:", sum(1 for k in out if k.startswith("gradsum_")), "message:", lines[0])

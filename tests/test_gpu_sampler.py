@@ -310,3 +310,23 @@ def test_large_ragged_molecules_sample_consistently(split):
     assert torch.isfinite(xa).all() and torch.isfinite(pa).all()
     assert torch.equal(xa, xb) and torch.equal(pa, pb)
     assert torch.equal(torch.cat([x1, x2]), xa) and torch.equal(torch.cat([p1, p2]), pa)
+
+
+@pytest.mark.parametrize("tag", ["dict_guided", "dict_plain"])
+def test_dict_valued_target_properties_match_reference(tag):
+    """Dict-valued target_properties (generation.py:689-757): the reference's model call fails on them and returns
+    zero predictions (model1.py:337, :757-764); the generator reproduces exactly that (zero conditional prediction,
+    guidance combination as generation.py:442-443).  Final state of a 20-step DDPM against the reference's
+    (tests/golden/quirk.npz), with the reference's own draws."""
+    f = golden("quirk.npz")
+    T, n, seed = [int(v) for v in f[tag + "_meta"]]
+    gen = _gen(T)
+    noise = SeededNoise(seed, n, T)
+    tp = {"molecular_weight": 350.0, "logp": 2.5, "qed": 0.8}
+    x, pos, _, _ = gen.sample_batch([n], tp, float(f[tag + "_scale"]), 0.9, noise=noise)
+    fx, fp = torch.from_numpy(f[tag + "_final_x"]), torch.from_numpy(f[tag + "_final_pos"])
+    torch.testing.assert_close(x.cpu(), fx, rtol=1e-3, atol=1e-3 * float(fx.abs().max()))
+    torch.testing.assert_close(pos.cpu(), fp, rtol=1e-3, atol=1e-3 * float(fp.abs().max()))
+    # and through the public entry point with the library's own noise: runs, returns the reference's keys
+    out = gen.generate_with_research_protocols(num_molecules=3, target_properties=tp, atom_range=(10, 16), use_ddim=False)
+    assert gen.last_stats["attempted"] == 3 and all(o["target_properties"] == tp for o in out)

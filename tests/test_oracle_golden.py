@@ -312,3 +312,18 @@ def test_reference_loader_shapes_match_reference():
     # the property encoders are trained through the conditioning even though their loss is skipped
     assert sd["property_guidance.property_encoders.0.0.weight"].grad is not None
     assert sd["property_output.3.weight"].grad is None
+
+
+@pytest.mark.parametrize("tag", ["dict_guided", "dict_plain"])
+def test_dict_valued_target_properties_match_reference(tag):
+    """generation.py:393-484 with a dict as target_properties (the scenarios of generation.py:689-757): the reference's
+    model call fails on it and returns zeros (model1.py:337, :757-764), so the conditional prediction is zero."""
+    f = golden("quirk.npz")
+    T, n, seed = [int(v) for v in f[tag + "_meta"]]
+    sd = seed0_state_dict(timesteps=T)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        x, pos = oracle.ddpm_sample(sd, oracle.cosine_schedule(T), n, lambda shape: torch.randn(*shape, generator=g),
+                                    {"qed": 0.8}, float(f[tag + "_scale"]), 0.9)
+    torch.testing.assert_close(x, torch.from_numpy(f[tag + "_final_x"]), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(pos, torch.from_numpy(f[tag + "_final_pos"]), rtol=1e-4, atol=1e-4)

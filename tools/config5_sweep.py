@@ -2,7 +2,7 @@
 template ligands (seeded uniform sizes), 1000-step DDPM, MLP GEMMs in split-operand mode, batches of at most
 32 768 atoms, results copied to the host and judged there (finite, gates, distinct fingerprints).
 
-Usage: python tools/config5_sweep.py [molecules] [out.json] [split(1|0)]
+Usage: python tools/config5_sweep.py [molecules] [out.json] [split(1|0)] [atoms per packed batch]
 Prints a progress line per 2 000 molecules on stderr and one JSON object on stdout (and into out.json)."""
 import json
 import os
@@ -24,7 +24,7 @@ def fingerprint(x, pos):
     return hash((types, tuple(np.round(np.sort(d[iu]), 1).tolist())))
 
 
-def run(n_mols=100000, split=True, chunk=2000, device="cuda", log=sys.stderr):
+def run(n_mols=100000, split=True, chunk=2000, device="cuda", log=sys.stderr, batch_atoms=None):
     from diffusion_model_ligandmol_generation_amd import ResearchAccurateDiffusionModel
     from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
     g = torch.Generator().manual_seed(555)
@@ -33,12 +33,14 @@ def run(n_mols=100000, split=True, chunk=2000, device="cuda", log=sys.stderr):
     model = ResearchAccurateDiffusionModel(max_atoms=128).to(device).eval()
     gen = ResearchValidatedGenerator(model)
     eng = model.engine()
-    prev = eng.set_split_gemm(bool(split))
+    gen.options = eng.options(gemm_mode=int(bool(split)))      # per call; the process-wide mode is left alone
+    if batch_atoms:
+        gen.batch_atoms = gen.batch_atoms_split = int(batch_atoms)
     finite = accepted = 0
     prints = set()
     gpu_s = 0.0
     t_all = time.time()
-    try:
+    if True:
         offset = 0
         for lo in range(0, n_mols, chunk):
             part = sizes[lo:lo + chunk]
@@ -56,11 +58,9 @@ def run(n_mols=100000, split=True, chunk=2000, device="cuda", log=sys.stderr):
             done = lo + len(part)
             print(f"[config5 sweep] {done}/{n_mols} molecules, {gpu_s:.1f} s sampling, {done / gpu_s:.1f} molecules/s, "
                   f"{time.time() - t_all:.1f} s wall", file=log, flush=True)
-    finally:
-        eng.set_split_gemm(prev)
     return {"workload": "ragged 10-128-atom template ligands (uniform sizes, seed 555), 1000-step DDPM, "
                         + ("split-operand bf16 MFMA GEMMs (fp32 accumulate)" if split else "fp32 matrix pipe")
-                        + ", batches of <= 32768 atoms, results copied to the host",
+                        + f", batches of <= {gen.batch_atoms_split if split else gen.batch_atoms} atoms, results copied to the host",
             "molecules": n_mols, "atoms": int(sum(sizes)), "ddpm_steps": 1000,
             "sampling_seconds": gpu_s, "wall_seconds_with_host_checks": time.time() - t_all,
             "molecules_per_s": n_mols / gpu_s, "atom_steps_per_s": sum(sizes) * 1000.0 / gpu_s,
@@ -72,7 +72,8 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     path = sys.argv[2] if len(sys.argv) > 2 else None
     sp = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
-    out = run(n, sp)
+    ba = int(sys.argv[4]) if len(sys.argv) > 4 else None
+    out = run(n, sp, chunk=max(2000, (ba or 0) // 30), batch_atoms=ba)
     line = json.dumps(out)
     if path:
         with open(path, "w") as fh:
