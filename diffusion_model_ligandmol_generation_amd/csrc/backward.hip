@@ -18,9 +18,14 @@ struct BwdLayout {
   size_t e256a, e4;
   size_t dmod[3], b256a, b256b, b256c, b256d, b512, b2048, b8, bhid;
   size_t wt;   // transposed weight block of the dX GEMM in flight (<= 1536 x 256 elements, fp32 or split bf16: 6 bytes each)
+  size_t wt_all, wt_all_floats;   // every weight block the input-gradient GEMMs need transposed, filled by ONE launch
   size_t pool, pool_bytes;   // single-use buffers: everything a weight-gradient launch on the side stream reads
   size_t total;
 };
+// Floats of all pre-transposed weight blocks (see wt_prepare): heads 3 x 256 x 256, per attention layer FFN 2 x 256 x 1024,
+// out-projection 256 x 256, in-projection 768 x 256, adaLN 1536 x 256; per E(3) layer six 256 x 256 blocks and the
+// 128 x 256 coordinate gate; second time-MLP layer 256 x 512.
+#define WT_ALL_FLOATS (3 * 65536 + 3 * (2 * 262144 + 65536 + 196608 + 393216) + 3 * (6 * 65536 + 32768) + 131072)
 // Bytes of the single-use pool: one buffer per use of every tensor that a weight-gradient launch reads (heads,
 // per attention layer, per E(3) layer, embeddings), each rounded like `take` below.
 static size_t bwd_pool_bytes(int64_t N, int64_t E) {
@@ -46,6 +51,8 @@ static void bwd_layout(BwdLayout* L, int64_t N, int64_t E, int32_t B) {
   L->b256d = take((size_t)B * 256); L->b512 = take((size_t)B * 512); L->b2048 = take((size_t)B * 2048);
   L->b8 = take((size_t)B * 8); L->bhid = take((size_t)B * 512);
   L->wt = take(1536 * 256 * 3 / 2);
+  L->wt_all_floats = WT_ALL_FLOATS;
+  L->wt_all = take(L->wt_all_floats);
   L->pool = off;
   L->pool_bytes = bwd_pool_bytes(N, E);
   off += L->pool_bytes;
@@ -124,6 +131,40 @@ struct SideStream {
 // Scratch for the transposed weight block (set per ligdiff_backward call from its workspace).
 static thread_local float* g_wt_scratch = nullptr;
 
+// All weight blocks that gemm_dx needs transposed (fp32 pipe), transposed by ONE launch at the start of the sweep
+// instead of one small launch in front of every input-gradient GEMM (39 per step).  gemm_dx looks its block up by
+// (pointer, leading dimension, K, columns); a block that is not in the table is transposed on the spot as before.
+struct WtEntry { const float* W; int ldw, K, ncols, tile0; float* dst; };
+struct WtBatch { WtEntry e[48]; int n, tiles; };
+static thread_local WtBatch g_wt_table;
+__global__ __launch_bounds__(256) void k_transpose_many(WtBatch b) {
+  __shared__ float tile[32][33];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.e[i + 1].tile0) ++i;
+  const WtEntry en = b.e[i];
+  const int t = blockIdx.x - en.tile0, tc = en.ncols >> 5;
+  const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;   // rows = K index of W, columns = ncols index
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) tile[k][tx] = en.W[(size_t)(r0 + k) * en.ldw + c0 + tx];
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) en.dst[(size_t)(c0 + k) * en.K + r0 + tx] = tile[tx][k];
+}
+static const float* wt_lookup(const float* W, int ldw, int K, int ncols) {
+  const WtBatch& b = g_wt_table;
+  for (int i = 0; i < b.n; ++i)
+    if (b.e[i].W == W && b.e[i].ldw == ldw && b.e[i].K == K && b.e[i].ncols == ncols) return b.e[i].dst;
+  return nullptr;
+}
+static bool wt_add(const float* W, int ldw, int K, int ncols, float* base, size_t cap_floats, size_t* used) {
+  WtBatch& b = g_wt_table;
+  if (b.n >= 48 || (K & 31) || (ncols & 31) || *used + (size_t)K * ncols > cap_floats) return false;
+  b.e[b.n] = WtEntry{W, ldw, K, ncols, b.tiles, base + *used};
+  b.tiles += (K >> 5) * (ncols >> 5);
+  *used += (size_t)K * ncols;
+  ++b.n;
+  return true;
+}
+
 // Measurement hook (ligdiff_backward_timed): the `want`-th launch of the wide weight-gradient kernel
 // gemm_dw_kernel<4> of a backward pass, counted in launch order, is bracketed by two events.
 struct BwdProbe { int want, seen, hits; int64_t nout, kin, rows; hipEvent_t e0, e1; };
@@ -170,9 +211,13 @@ static void gemm_dx(const float* dY, int lddy, int M, int K, const float* W, int
                          dim3(512), 0, s, g, sw, APtrPlain{dY, lddy}, e);
       return;
     }
-    hipLaunchKernelGGL(k_transpose_block, dim3(ceil_div(ncols, 32), ceil_div(K, 32)), dim3(256), 0, s, W, K, ncols, ldw,
-                       g_wt_scratch);
-    GemmCore g = core_blocks(M, K, 256, g_wt_scratch, K, ncols / 256, 256);
+    const float* wt = wt_lookup(W, ldw, K, ncols);
+    if (wt == nullptr) {
+      hipLaunchKernelGGL(k_transpose_block, dim3(ceil_div(ncols, 32), ceil_div(K, 32)), dim3(256), 0, s, W, K, ncols, ldw,
+                         g_wt_scratch);
+      wt = g_wt_scratch;
+    }
+    GemmCore g = core_blocks(M, K, 256, wt, K, ncols / 256, 256);
     EpiBwdStore<8, MUL, ACCUM> e{M, ncols, C, ldc, pre, ldp, 1.0f, ds};
     launch_gemm_cs(g, APtrPlain{dY, lddy}, e, ncols / 256, s);
     return;
@@ -289,6 +334,31 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
   const int nb4N = ceil_div(N, 4), nb4B = ceil_div(B, 4);
   float* dxa = T(L.dxa);
   g_wt_scratch = T(L.wt);
+  g_wt_table.n = 0; g_wt_table.tiles = 0;
+  struct WtTableScope { ~WtTableScope() { g_wt_table.n = 0; } } wt_table_scope;   // entries point into this call's workspace
+  static const bool wt_batch = [] { const char* e = getenv("LIGDIFF_WT_BATCH"); return !(e != nullptr && e[0] == '0'); }();   // A/B switch
+  if (wt_batch && use_cs() && !split_gemm_enabled()) {
+    float* base = T(L.wt_all);
+    size_t used = 0;
+    auto add = [&](const float* W, int ldw, int K, int ncols) { (void)wt_add(W, ldw, K, ncols, base, L.wt_all_floats, &used); };
+    for (int h = 0; h < 3; ++h) add(w[W_HEAD(h, HEAD_W0)], 256, 256, 256);
+    for (int l = 0; l < 3; ++l) {
+      add(w[W_DIT(l, DIT_FF3_W)], 1024, 256, 1024);
+      add(w[W_DIT(l, DIT_FF0_W)], 256, 1024, 256);
+      add(w[W_DIT(l, DIT_OUT_W)], 256, 256, 256);
+      add(w[W_DIT(l, DIT_INP_W)], 256, 768, 256);
+      add(w[W_DIT(l, DIT_ADA_W)], 256, 1536, 256);
+      add(w[W_E3(l, E3_NN2_W)], 256, 256, 256);
+      add(w[W_E3(l, E3_NN0_W)], 512, 256, 256);
+      add(w[W_E3(l, E3_NN0_W)] + 256, 512, 256, 256);
+      add(w[W_E3(l, E3_CN0_W)], 256, 128, 256);
+      add(w[W_E3(l, E3_EN2_W)], 256, 256, 256);
+      add(w[W_E3(l, E3_EN0_W)], 544, 256, 256);
+      add(w[W_E3(l, E3_EN0_W)] + 256, 544, 256, 256);
+    }
+    add(w[W_T2_W], 512, 256, 512);
+    if (g_wt_table.n > 0) hipLaunchKernelGGL(k_transpose_many, dim3(g_wt_table.tiles), dim3(256), 0, s, g_wt_table);
+  }
   SideStream side;
   side.init(s);
   struct JoinAtExit {   // also on the error returns below: nothing stays behind on the side stream unobserved
