@@ -127,6 +127,9 @@ SIGNATURES = {
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_size_t, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_float),
                                          C.POINTER(C.c_int64)]),
+    "ligdiff_adamw_workspace_bytes": (C.c_size_t, []),
+    "ligdiff_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64] + [C.c_float] * 8
+                           + [C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ligdiff_edm_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                       C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),

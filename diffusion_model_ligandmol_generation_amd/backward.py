@@ -85,6 +85,8 @@ class ScoreNetworkFunction(torch.autograd.Function):
         if st.grad_group is not None:
             from .parallel import allreduce_sum_
             allreduce_sum_(flat, st.grad_group)
+        # the flat buffer and where each parameter's gradient sits in it: the fused optimiser step works on it directly
+        eng.last_flat = {"flat": flat, "offsets": {n: o for n, o in zip([n for n in eng.names if _has_grad_slot(n)], offs)}}
         # parameters that did not take part get no gradient (as autograd would report them):
         # the optimiser then leaves them alone instead of applying weight decay to them
         has_props = bool(ctx.flags & _lib.FWD_PROPERTIES)

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 pids=()
-for f in chain_dit_mol_heads chain_dit_mol chain_dit_row_heads chain_dit_row forward backward chain_e3 sampler api pack loss consistency; do
+for f in chain_dit_mol_heads chain_dit_mol chain_dit_row_heads chain_dit_row forward backward chain_e3 sampler api pack loss consistency optim; do
   if [ -f $f.hip ]; then
     hipcc $FLAGS -c $f.hip -o $f.o &
     pids+=($!)

@@ -44,8 +44,9 @@ class ResearchAccurateTrainer:
         # what train.py:327-343 / :388-397 does: one row for every molecule, PILOT loss family skipped.  False: such
         # a tensor is refused, because that behaviour is almost certainly not what a caller wants.
         self.reference_collate_quirk = reference_collate_quirk
-        self.optimizer = torch.optim.AdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay,
-                                           betas=(0.9, 0.999), eps=1e-8)                      # train.py:47-53
+        from .optim import FusedAdamW      # a torch.optim.AdamW whose clip + step run in the HIP library when they can
+        self.optimizer = FusedAdamW(self.model.parameters(), lr=lr, weight_decay=weight_decay,
+                                    betas=(0.9, 0.999), eps=1e-8)                             # train.py:47-53
         self.warmup_steps = 1000
         self.scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda=self._edm_lr_schedule)
         self.chemical_constants = chemical_constants
@@ -219,8 +220,11 @@ class ResearchAccurateTrainer:
         loss_dict = self._compute_research_exact_loss(batch, training=True, draws=draws)
         loss_dict["total_loss"].backward()
         self._allreduce_gradients()
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=1.0)
-        self.optimizer.step()
+        if hasattr(self.optimizer, "clip_and_step"):      # train.py:196-197 as two launches over the flat gradient buffer
+            self.optimizer.clip_and_step(self.model, max_norm=1.0)
+        else:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=1.0)
+            self.optimizer.step()
         self.step_count += 1
         return loss_dict
 

@@ -342,6 +342,26 @@ int ligdiff_loss_partial(const ligdiff_loss_args* args, float* sums8, void* stre
 int ligdiff_loss_finish(const ligdiff_loss_args* args, const float* sums8, float upstream,
                         float* losses32, float* d_atom, float* d_pos, float* d_prop, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Optimiser step.  Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) + AdamW.step() of train.py:196-197
+ * for parameters whose gradients are slices of ONE flat fp32 buffer (what the backward pass of this library's
+ * Python binding produces): one reduction for the global norm and one multi-tensor update launch.
+ *   table (device): n tensors x { float* param; float* exp_avg; float* exp_avg_sq; int64 grad_offset (elements into
+ *   flat_grad); int64 numel };  chunk_tensor / chunk_start (device int32 [n_chunks]): workgroup c updates elements
+ *   [2048 chunk_start[c], +2048) of tensor chunk_tensor[c].
+ * compute_norm != 0: norm2[0] = ||flat_grad||_2 over all flat_numel elements, norm2[1] = min(1, max_norm / (norm + 1e-6))
+ * (1 if max_norm <= 0); compute_norm == 0 reuses norm2 as it stands (a second group of tensors at another step count).
+ * Every gradient element of the listed tensors is multiplied by norm2[1] in place (as clip_grad_norm_ leaves it), then
+ *   p *= 1 - lr wd;  m += (g - m)(1 - beta1);  v = v beta2 + g^2 (1 - beta2);
+ *   p -= lr / bias_correction1 * m / (sqrt(v) / bias_correction2_sqrt + eps)          (torch.optim.AdamW, no amsgrad).
+ * ------------------------------------------------------------------------------- */
+size_t ligdiff_adamw_workspace_bytes(void);
+int ligdiff_adamw_step(const void* table_dev, const int32_t* chunk_tensor_dev, const int32_t* chunk_start_dev,
+                       int32_t n_chunks, float* flat_grad, int64_t flat_numel, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float bias_correction1, float bias_correction2_sqrt,
+                       float max_norm, int32_t compute_norm, float* norm2_dev, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* Process-wide switch for how the forward pass (and the sampling loops built on it), and the
  * input-gradient products of ligdiff_backward, multiply their fp32 matrices; returns the previous setting.  0 (default, or LIGDIFF_GEMM_SPLIT unset in the
  * environment): v_mfma_f32_32x32x2_f32.  1: each fp32 operand is the exact sum of three bf16 numbers
