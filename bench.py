@@ -238,7 +238,7 @@ def uniform_sizes(n, lo, hi, seed):
 
 
 # ------------------------------------------------------------------ extra legs
-def leg_config3_train_step(ctx, steps=5, warmup=2, mols_per_rank=512):
+def leg_config3_train_step(ctx, steps=10, warmup=3, mols_per_rank=512):
     """BASELINE configs[2]: data-parallel training step on drug-like ragged ligands (10-64 atoms, bond
     templates), 512 molecules per GPU (global batch 4096 on 8 GPUs): EDM noise/loss step, forward
     with saved activations, backward, ONE flat gradient all-reduce over all ranks, clip, AdamW."""
@@ -261,12 +261,20 @@ def leg_config3_train_step(ctx, steps=5, warmup=2, mols_per_rank=512):
     model = build_model(dev, 100, train=True)
     trainer = ResearchAccurateTrainer(model, [], [], [], process_group=ctx.group)
     dt, _ = ctx.timed(lambda i: trainer.train_step(b), warmup, steps)
+    # the same step with the forward and input-gradient GEMMs in split-operand mode (per call, through the model's
+    # library options; the weight-gradient GEMMs stay on the fp32 pipe)
+    model.library_options = model.engine().options(gemm_mode=1)
+    try:
+        dt_split, _ = ctx.timed(lambda i: trainer.train_step(b), warmup, steps)
+    finally:
+        model.library_options = None
     n_atoms_global = ctx.sum_over_ranks(N)
     out = {"workload": "configs[2]: ragged 10-64-atom template ligands, 512 molecules per GPU, data-parallel training "
                        "step (EDM loss, forward, backward, flat gradient all-reduce, clip, AdamW), fp32, train mode",
            "molecules_per_gpu": mols_per_rank, "global_batch": mols_per_rank * ctx.world,
            "atoms_global": int(n_atoms_global), "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "molecules_per_s": mols_per_rank * ctx.world * steps / dt,
+           "ms_per_step_split_operand_mode": dt_split / steps * 1e3,
            "collective": (("gloo (rehearsal)" if ctx.rehearse else "RCCL all-reduce, 26.4 MB fp32 per step")
                           if ctx.world > 1 else "none (one rank)")}
     if ctx.world > 1:      # the gradient all-reduce on its own: one flat fp32 buffer of the gradients' size

@@ -6,7 +6,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .engine import _ptr, _stream
+from .engine import _opt, _ptr, _stream
 
 
 def _has_grad_slot(name):
@@ -29,15 +29,16 @@ class ScoreNetworkFunction(torch.autograd.Function):
         lib = eng.lib
         N, B = graph.n_atoms, graph.n_mols
         flags = st.flags | _lib.FWD_SAVE_FOR_BACKWARD
-        nbytes = lib.ligdiff_forward_workspace_bytes(N, graph.n_edges, B, flags)
+        nbytes = lib.ligdiff_forward_workspace_bytes_opt(N, graph.n_edges, B, flags, _opt(st.options))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)   # kept alive until backward
         atom = torch.empty(N, 119, dtype=torch.float32, device=eng.device)
         posp = torch.empty(N, 3, dtype=torch.float32, device=eng.device)
         prop = torch.empty(B, 15, dtype=torch.float32, device=eng.device)
         with torch.cuda.device(eng.device):
-            rc = lib.ligdiff_forward_train(eng.table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.t), None,
-                                           _ptr(st.props), flags, _ptr(atom), _ptr(posp), _ptr(prop), _ptr(ws),
-                                           ws.numel(), _stream(), C.byref(st.dropout) if st.dropout is not None else None)
+            rc = lib.ligdiff_forward_opt(eng.table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.t), None,
+                                         _ptr(st.props), flags, _ptr(atom), _ptr(posp), _ptr(prop), _ptr(ws),
+                                         ws.numel(), _stream(), C.byref(st.dropout) if st.dropout is not None else None,
+                                         _opt(st.options))
         check(rc, "ligdiff_forward_train(save)")
         ctx.st, ctx.ws, ctx.flags = st, ws, flags
         st.eng.last_forward = (ws, flags) if st.keep_state else None   # for consistency() right after this call
@@ -70,13 +71,13 @@ class ScoreNetworkFunction(torch.autograd.Function):
                 gi += 1
             else:
                 table[i] = None
-        nbytes = lib.ligdiff_backward_workspace_bytes(N, graph.n_edges, B)
+        nbytes = lib.ligdiff_backward_workspace_bytes_opt(N, graph.n_edges, B, _opt(st.options))
         bws = eng.workspace(nbytes)
         with torch.cuda.device(dev):
-            rc = lib.ligdiff_backward_train(eng.table, table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.props),
-                                            ctx.flags, _ptr(d_atom), _ptr(d_pos), _ptr(d_prop), _ptr(ctx.ws), _ptr(bws),
-                                            bws.numel(), _stream(),
-                                            C.byref(st.dropout) if st.dropout is not None else None)
+            rc = lib.ligdiff_backward_opt(eng.table, table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.props),
+                                          ctx.flags, _ptr(d_atom), _ptr(d_pos), _ptr(d_prop), _ptr(ctx.ws), _ptr(bws),
+                                          bws.numel(), _stream(),
+                                          C.byref(st.dropout) if st.dropout is not None else None, _opt(st.options))
         check(rc, "ligdiff_backward_train")
         ctx.ws = None
         # data parallel: the parameter gradients of one backward pass are ONE zero-padded buffer, so the
@@ -107,7 +108,8 @@ class ScoreNetworkFunction(torch.autograd.Function):
     @staticmethod
     def run(model, eng, graph, x, pos, t, properties, null_cond, keep_state=False, dropout=None):
         """``model.grad_allreduce_group`` (set by a data-parallel trainer, else absent): process group
-        over which backward sums the parameter gradients."""
+        over which backward sums the parameter gradients.  ``model.library_options`` (an engine Options struct, else
+        absent): per-call options of the forward / backward pair, e.g. the split-operand GEMM mode."""
         N, B = graph.n_atoms, graph.n_mols
         x = x.detach().contiguous().float()
         pos = pos.detach().contiguous().float()
@@ -129,7 +131,7 @@ class ScoreNetworkFunction(torch.autograd.Function):
         sd = dict(model.state_dict(keep_vars=True))
         params = [sd[n] for n in eng.names if _has_grad_slot(n)]
         st = _Ctx(eng=eng, graph=graph, x=x, pos=pos, t=t, props=props, flags=flags, keep_state=keep_state, dropout=dropout,
-                  grad_group=getattr(model, "grad_allreduce_group", None))
+                  grad_group=getattr(model, "grad_allreduce_group", None), options=getattr(model, "library_options", None))
         return ScoreNetworkFunction.apply(st, *params)
 
 
