@@ -1,9 +1,10 @@
 """The 100k-molecule sampling sweep of the mixed-size ragged workload, run for real on one GPU: 10-128-atom
-template ligands (seeded uniform sizes), 1000-step DDPM, MLP GEMMs in split-operand mode, batches of at most
-32 768 atoms, results copied to the host and judged there (finite, gates, distinct fingerprints).
+template ligands (seeded uniform sizes), 1000-step DDPM, MLP GEMMs in split-operand mode, packed batches of the
+generator's own size (131 072 atoms in split-operand mode, 32 768 on the fp32 pipe), results copied to the host and
+judged there (finite, gates, distinct fingerprints).  The request is handed to the generator 16 000 molecules at a time.
 
 Usage: python tools/config5_sweep.py [molecules] [out.json] [split(1|0)] [atoms per packed batch]
-Prints a progress line per 2 000 molecules on stderr and one JSON object on stdout (and into out.json)."""
+Prints a progress line per 16 000 molecules on stderr and one JSON object on stdout (and into out.json)."""
 import json
 import os
 import sys
@@ -24,7 +25,7 @@ def fingerprint(x, pos):
     return hash((types, tuple(np.round(np.sort(d[iu]), 1).tolist())))
 
 
-def run(n_mols=100000, split=True, chunk=2000, device="cuda", log=sys.stderr, batch_atoms=None):
+def run(n_mols=100000, split=True, chunk=16000, device="cuda", log=sys.stderr, batch_atoms=None):
     from diffusion_model_ligandmol_generation_amd import ResearchAccurateDiffusionModel
     from diffusion_model_ligandmol_generation_amd.generation import ResearchValidatedGenerator
     g = torch.Generator().manual_seed(555)
@@ -73,7 +74,7 @@ if __name__ == "__main__":
     path = sys.argv[2] if len(sys.argv) > 2 else None
     sp = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
     ba = int(sys.argv[4]) if len(sys.argv) > 4 else None
-    out = run(n, sp, chunk=max(2000, (ba or 0) // 30), batch_atoms=ba)
+    out = run(n, sp, batch_atoms=ba)
     line = json.dumps(out)
     if path:
         with open(path, "w") as fh:
