@@ -607,7 +607,7 @@ def run_rank(args):
         agg_gbs = bytes_agg / (ms_agg * 1e-3) / 1e9
         roofline_agg = {"kernel": "k_aggregate (e3_*.aggregate)", "bound": "hbm", "achieved": agg_gbs,
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": agg_gbs / PEAK_HBM_GBS,
-                        "traffic": traffic_of(traffic, "k_aggregate("), "traffic_source": traffic_src,
+                        "traffic": traffic_of(traffic, "k_aggregate"), "traffic_source": traffic_src,
                         "avg_launch_ms": ms_agg}
         out = {
             "metric": "sampled molecules/sec (1000-step DDPM)", "value": value, "unit": "molecules/s",
