@@ -89,22 +89,11 @@ static inline bool half_tiles(int M, int nb) {
   return on && (2 * n + cu - 1) / cu < 2 * ((n + cu - 1) / cu);
 }
 // Launches of very few rows: with at most one 32-row workgroup per CU the four-wave 32-row form (gemm_cs_quarter_kernel)
-// halves the chain of MFMAs a wave runs once more.  Beyond that size the same count decides: a SIMD of the fullest CU
-// runs ceil(n32 / CUs) half-length chains in the 32-row form against 2 ceil(n64 / CUs) in the 64-row and
-// 4 ceil(n128 / CUs) in the 128-row form, and the 32-row form is taken when it is strictly the shortest (18 756 rows
-// x one column block: 3 against 4 and 4; LIGDIFF_GEMM_TILE32=0 keeps it to the one-workgroup-per-CU case).
-// Same bits, same switch.
+// halves the chain of MFMAs a wave runs once more.  Same bits, same switch.
 static inline bool quarter_tiles(int M, int nb) {
   static const bool on = [] { const char* e = getenv("LIGDIFF_GEMM_TILE64"); return !(e != nullptr && e[0] == '0'); }();
-  static const bool wide = [] { const char* e = getenv("LIGDIFF_GEMM_TILE32"); return !(e != nullptr && e[0] == '0'); }();
-  if (!on) return false;
-  const int64_t cc = chain_concurrent_calls(), cu = device_cus();
-  const int64_t n32 = (int64_t)ceil_div(M, 32) * nb * cc;
-  if (n32 <= cu) return true;
-  if (!wide) return false;
-  const int64_t n64 = (int64_t)ceil_div(M, 64) * nb * cc, n128 = (int64_t)ceil_div(M, 128) * nb * cc;
-  const int64_t l32 = (n32 + cu - 1) / cu, l64 = 2 * ((n64 + cu - 1) / cu), l128 = 4 * ((n128 + cu - 1) / cu);
-  return l32 < l64 && l32 < l128;
+  const int64_t n = (int64_t)ceil_div(M, 32) * nb * chain_concurrent_calls();
+  return on && n <= device_cus();
 }
 // Split-operand mode (gemm4.h): while a cache is installed for the calling thread, the column-split
 // launches below convert each weight block they meet for the first time (one small launch on the
