@@ -462,16 +462,16 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
       const float* att_l = A(F.att[l]);
       const float* lse_l = A(F.lse[l]);
       if (tk == 1)
-        hipLaunchKernelGGL((k_attention_bwd_mfma<1, 4, true>), dim3(ceil_div((long)B * 8, 4)), dim3(256), 4 * 32 * 134 * 4, s,
+        hipLaunchKernelGGL((k_attention_bwd_mfma<1, 4, true>), dim3(ceil_div((long)B * 8, 4)), dim3(512), 4 * 32 * 134 * 4, s,
                            qkv_l, att_l, t256c, lse_l, g->mol_ptr, dqkv, B, d_att);
       else if (tk == 2)
-        hipLaunchKernelGGL((k_attention_bwd_mfma<2, 4, true>), dim3(ceil_div((long)B * 8, 4)), dim3(256), 4 * 64 * 134 * 4, s,
+        hipLaunchKernelGGL((k_attention_bwd_mfma<2, 4, true>), dim3(ceil_div((long)B * 8, 4)), dim3(512), 4 * 64 * 134 * 4, s,
                            qkv_l, att_l, t256c, lse_l, g->mol_ptr, dqkv, B, d_att);
       else if (tk == 3)
-        hipLaunchKernelGGL((k_attention_bwd_mfma<3, 2, true>), dim3(ceil_div((long)B * 8, 2)), dim3(128), 2 * 96 * 134 * 4, s,
+        hipLaunchKernelGGL((k_attention_bwd_mfma<3, 2, true>), dim3(ceil_div((long)B * 8, 2)), dim3(256), 2 * 96 * 134 * 4, s,
                            qkv_l, att_l, t256c, lse_l, g->mol_ptr, dqkv, B, d_att);
       else
-        hipLaunchKernelGGL((k_attention_bwd_mfma<4, 2, true>), dim3(ceil_div((long)B * 8, 2)), dim3(128), 2 * 128 * 134 * 4, s,
+        hipLaunchKernelGGL((k_attention_bwd_mfma<4, 2, true>), dim3(ceil_div((long)B * 8, 2)), dim3(256), 2 * 128 * 134 * 4, s,
                            qkv_l, att_l, t256c, lse_l, g->mol_ptr, dqkv, B, d_att);
     } else if (getenv("LIGDIFF_ATT_BWD_V1") != nullptr) {   // scalar reference kernel (A/B switch used by the tests)
       if (g->max_mol_atoms <= 64)
@@ -486,16 +486,16 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
       const float* att_l = A(F.att[l]);
       const float* lse_l = A(F.lse[l]);
       if (tk == 1)
-        hipLaunchKernelGGL((k_attention_bwd_mfma<1, 4>), dim3(ceil_div((long)B * 8, 4)), dim3(256), 4 * 32 * 134 * 4, s, qkv_l,
+        hipLaunchKernelGGL((k_attention_bwd_mfma<1, 4>), dim3(ceil_div((long)B * 8, 4)), dim3(512), 4 * 32 * 134 * 4, s, qkv_l,
                            att_l, t256c, lse_l, g->mol_ptr, dqkv, B);
       else if (tk == 2)
-        hipLaunchKernelGGL((k_attention_bwd_mfma<2, 4>), dim3(ceil_div((long)B * 8, 4)), dim3(256), 4 * 64 * 134 * 4, s, qkv_l,
+        hipLaunchKernelGGL((k_attention_bwd_mfma<2, 4>), dim3(ceil_div((long)B * 8, 4)), dim3(512), 4 * 64 * 134 * 4, s, qkv_l,
                            att_l, t256c, lse_l, g->mol_ptr, dqkv, B);
       else if (tk == 3)
-        hipLaunchKernelGGL((k_attention_bwd_mfma<3, 2>), dim3(ceil_div((long)B * 8, 2)), dim3(128), 2 * 96 * 134 * 4, s, qkv_l,
+        hipLaunchKernelGGL((k_attention_bwd_mfma<3, 2>), dim3(ceil_div((long)B * 8, 2)), dim3(256), 2 * 96 * 134 * 4, s, qkv_l,
                            att_l, t256c, lse_l, g->mol_ptr, dqkv, B);
       else
-        hipLaunchKernelGGL((k_attention_bwd_mfma<4, 2>), dim3(ceil_div((long)B * 8, 2)), dim3(128), 2 * 128 * 134 * 4, s, qkv_l,
+        hipLaunchKernelGGL((k_attention_bwd_mfma<4, 2>), dim3(ceil_div((long)B * 8, 2)), dim3(256), 2 * 128 * 134 * 4, s, qkv_l,
                            att_l, t256c, lse_l, g->mol_ptr, dqkv, B);
     }
     {

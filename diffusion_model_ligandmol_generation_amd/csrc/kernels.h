@@ -492,12 +492,14 @@ __global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict_
 // product with V (nn.MultiheadAttention in train mode, model1.py:263-267); the row sum l and the
 // saved log-sum-exp stay those of the unmasked softmax.
 template <int TK, bool DROP = false>
-__global__ __launch_bounds__(256) void k_attention_reg(const float* __restrict__ qkv,
+__global__ __launch_bounds__(256, TK >= 3 ? 4 : 1) void k_attention_reg(const float* __restrict__ qkv,
                                                        const int32_t* __restrict__ mol_ptr,
                                                        float* __restrict__ out, float* __restrict__ lse_out,
                                                        int n_mols, DropSite drop = DropSite{}) {
   constexpr int ITEMS = 8 * TK;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index, and with it the molecule, head, query tile and every tile bound below, is the same for all
+  // lanes: kept in scalar registers, so the tile branches are scalar branches and the row addresses 32-bit offsets
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int item = blockIdx.x * 4 + wave;
   const int mol = item / ITEMS, rem = item % ITEMS;
   const int head = rem / TK, qt = rem % TK;
@@ -510,41 +512,48 @@ __global__ __launch_bounds__(256) void k_attention_reg(const float* __restrict__
   const float* base = qkv + (size_t)a0 * 768 + head * 32;
   float q[16];
   {
-    const float* qp = base + (size_t)(qi < n ? qi : n - 1) * 768 + 16 * h;
+    const uint32_t qo = (uint32_t)(qi < n ? qi : n - 1) * 768u + 16u * h;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(qp + c * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + qo + c * 4);
       q[c * 4 + 0] = v[0] * scale; q[c * 4 + 1] = v[1] * scale; q[c * 4 + 2] = v[2] * scale; q[c * 4 + 3] = v[3] * scale;
     }
   }
   // key tiles beyond the molecule (t * 32 >= n, the same for every lane of the wave) are skipped: their scores
-  // are masked to -inf below and their probabilities are exactly 0
+  // are masked to -inf below and their probabilities are exactly 0.  The K rows of tile t + 1 are requested before
+  // the products of tile t, so that only two tiles of operands are live at a time.
   f32x16 sc[TK];
+  f32x4 kf[2][4];
+  auto load_k = [&](int t, f32x4* dst) {
+    const int kr = t * 32 + fi;
+    const uint32_t ko = (uint32_t)(kr < n ? kr : n - 1) * 768u + 256u + 16u * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = *reinterpret_cast<const f32x4*>(base + ko + c * 4);
+  };
+  load_k(0, kf[0]);
 #pragma unroll
   for (int t = 0; t < TK; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
     if (t * 32 < n) {
-      const int kr = t * 32 + fi;
-      const float* kp = base + (size_t)(kr < n ? kr : n - 1) * 768 + 256 + 16 * h;
-      f32x4 kf[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const f32x4*>(kp + c * 4);
+      if (t + 1 < TK && (t + 1) * 32 < n) load_k(t + 1, kf[(t + 1) & 1]);
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e)   // A = K[t*32 + fi, 16h + 4c + e], B = scale Q[qi, same d]
-          sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c][e], q[c * 4 + e], sc[t], 0, 0, 0);
+          sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t & 1][c][e], q[c * 4 + e], sc[t], 0, 0, 0);
     }
   }
-  float vf[TK][16];   // V[j(r, h), d = fi], fetched while the softmax runs
-#pragma unroll
-  for (int t = 0; t < TK; ++t)
+  // V[j(r, h), d = fi]: tile 0 is fetched while the softmax runs, tile t + 1 while tile t multiplies
+  float vf[2][16];
+  auto load_v = [&](int t, float* dst) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int vr = t * 32 + G_ROW_ATT(r, h);
-      vf[t][r] = t * 32 < n ? base[(size_t)(vr < n ? vr : n - 1) * 768 + 512 + fi] : 0.f;
+      dst[r] = base[(uint32_t)(vr < n ? vr : n - 1) * 768u + 512u + fi];
     }
+  };
+  load_v(0, vf[0]);
   float m = -INFINITY;
 #pragma unroll
   for (int t = 0; t < TK; ++t)
@@ -581,8 +590,9 @@ __global__ __launch_bounds__(256) void k_attention_reg(const float* __restrict__
 #pragma unroll
   for (int t = 0; t < TK; ++t)
     if (t * 32 < n) {
+      if (t + 1 < TK && (t + 1) * 32 < n) load_v(t + 1, vf[(t + 1) & 1]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t][r], sc[t][r], o, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t & 1][r], sc[t][r], o, 0, 0, 0);
     }
   if (qi < n) {
     const float inv = 1.0f / l;

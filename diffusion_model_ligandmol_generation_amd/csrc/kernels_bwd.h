@@ -365,15 +365,22 @@ __global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__
 #define GB_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))
 // DROP: the forward pass multiplied the probabilities by the dropout mask Ms of site `drop`
 // (O = (P Ms) V): dV takes P Ms, dP = (dO V^T) Ms, and delta_i = dO_i . O_i is unchanged in form.
-template <int TK, int WPB, bool DROP = false>
-__global__ __launch_bounds__(WPB * 64) void k_attention_bwd_mfma(const float* __restrict__ qkv, const float* __restrict__ o,
+// PAIR: two waves per (molecule, head) - they fill the LDS images together, then one runs pass 1 and the other
+// pass 2 (the passes only read the images).  The images of a 64-atom head are 34 KiB, so a CU holds four of them:
+// with one wave per image each SIMD has a single wave whose loads, LDS reads, exponentials and MFMAs run one
+// after the other; with two, one wave's MFMAs cover the other's waits.  Every output element is computed by the
+// same instructions in the same order either way.
+template <int TK, int WPB, bool DROP = false, bool PAIR = true>
+__global__ __launch_bounds__(WPB * 64 * (PAIR ? 2 : 1)) void k_attention_bwd_mfma(const float* __restrict__ qkv, const float* __restrict__ o,
                                                                  const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                  const int32_t* __restrict__ mol_ptr,
                                                                  float* __restrict__ dqkv, int n_mols,
                                                                  DropSite drop = DropSite{}) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NP = TK * 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = PAIR ? wv % WPB : wv;     // image slot of the workgroup
+  const int role = PAIR ? wv / WPB : 0;      // PAIR: 0 runs pass 1, 1 runs pass 2
   const int item = blockIdx.x * WPB + wave;
   const int mol = item >> 3, head = item & 7;
   float* sq = smem + (size_t)wave * (NP * 134);
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(WPB * 64) void k_attention_bwd_mfma(const float* __
   float* sdel = slse + NP;
   int a0 = 0, n = 0;
   if (mol < n_mols) { a0 = mol_ptr[mol]; n = mol_ptr[mol + 1] - a0; }
-  for (int i = lane; i < NP * 8; i += 64) {   // 8 lanes per row, 4 columns each
+  for (int i = lane + 64 * role; i < NP * 8; i += PAIR ? 128 : 64) {   // 8 lanes per row, 4 columns each
     const int j = i >> 3, c = (i & 7) * 4;
     f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, v4 = q4, d4 = q4, o4 = q4;
     if (j < n) {
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(WPB * 64) void k_attention_bwd_mfma(const float* __
   // ---------------- pass 1: lane = query
 #pragma unroll 1
   for (int it = 0; it < TK; ++it) {
-    if (it * 32 >= n) break;
+    if (it * 32 >= n || (PAIR && role != 0)) break;
     const int qi = it * 32 + fi;
     float qreg[16], doreg[16];
 #pragma unroll
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(WPB * 64) void k_attention_bwd_mfma(const float* __
   // ---------------- pass 2: lane = key
 #pragma unroll 1
   for (int jt = 0; jt < TK; ++jt) {
-    if (jt * 32 >= n) break;
+    if (jt * 32 >= n || (PAIR && role != 1)) break;
     const int kj = jt * 32 + fi;
     float kreg[16], vreg[16];
 #pragma unroll
