@@ -33,17 +33,21 @@ class StepArgs(C.Structure):
                 ("seed", C.c_uint64), ("atom_offset", C.c_int64), ("n_atoms", C.c_int64)]
 
 
+MAX_LAYER_PAIRS = 8   # LIGDIFF_MAX_LAYER_PAIRS: E(3) / attention layers the weights table has slots for
+
+
 class Dropout(C.Structure):
     """struct ligdiff_dropout"""
-    _fields_ = [("seed", C.c_uint64), ("atom_offset", C.c_int64), ("p_attention", C.c_float * 3),
-                ("p_ffn_hidden", C.c_float * 3), ("p_ffn_out", C.c_float * 3), ("p_consistency", C.c_float * 2)]
+    _fields_ = [("seed", C.c_uint64), ("atom_offset", C.c_int64), ("p_attention", C.c_float * MAX_LAYER_PAIRS),
+                ("p_ffn_hidden", C.c_float * MAX_LAYER_PAIRS), ("p_ffn_out", C.c_float * MAX_LAYER_PAIRS),
+                ("p_consistency", C.c_float * 2)]
 
 
 class Options(C.Structure):
     """struct ligdiff_options: per-call choices (-1, or 0 for concurrent_calls, = not set)."""
     _fields_ = [("gemm_mode", C.c_int32), ("chain_mode", C.c_int32), ("concurrent_calls", C.c_int32),
                 ("edge_chain", C.c_int32), ("node_chain", C.c_int32), ("mol_wave", C.c_int32),
-                ("edge_reduce", C.c_int32), ("cfg_two_pass", C.c_int32)]
+                ("edge_reduce", C.c_int32), ("cfg_two_pass", C.c_int32), ("layer_pairs", C.c_int32)]
 
     def __init__(self, **fields):
         super().__init__()
@@ -147,6 +151,8 @@ SIGNATURES = {
     "ligdiff_set_chain_mode": (C.c_int, [C.c_int]),
     "ligdiff_forward_state_offsets": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int, C.POINTER(C.c_size_t),
                                                 C.POINTER(C.c_size_t)]),
+    "ligdiff_forward_state_offsets_opt": (C.c_int, [C.c_int64, C.c_int64, C.c_int32, C.c_int, C.POINTER(C.c_size_t),
+                                                C.POINTER(C.c_size_t), C.POINTER(Options)]),
     "ligdiff_consistency_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "ligdiff_consistency": (C.c_int, [C.c_void_p, C.POINTER(Graph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -35,4 +35,4 @@ def score_network_apply(model, data, t, properties=None, classifier_free_guidanc
         return ScoreNetworkFunction.run(model, eng, graph, data.x, data.pos, t, properties, classifier_free_guidance,
                                         keep_state, dropout)
     return eng.forward(graph, data.x, data.pos, t, properties, null_cond=classifier_free_guidance,
-                       keep_state=keep_state, dropout=dropout)
+                       keep_state=keep_state, dropout=dropout, options=getattr(model, "library_options", None))

@@ -6,13 +6,18 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .engine import _opt, _ptr, _stream
+from .engine import _ptr, _stream
 
 
 def _has_grad_slot(name):
     """Table entries that take part in the score network's backward: not the frequency table and
     not the consistency module, whose outputs reach no loss (train.py:519, :543, :559, :583)."""
     return name != "__time_freqs__" and not name.startswith("moldiff_consistency.")
+
+
+def _grad_names(eng):
+    """Names of the table slots this model fills that receive a gradient, in table order."""
+    return [n for n in eng.live_names if _has_grad_slot(n)]
 
 
 class _Ctx:
@@ -29,7 +34,7 @@ class ScoreNetworkFunction(torch.autograd.Function):
         lib = eng.lib
         N, B = graph.n_atoms, graph.n_mols
         flags = st.flags | _lib.FWD_SAVE_FOR_BACKWARD
-        nbytes = lib.ligdiff_forward_workspace_bytes_opt(N, graph.n_edges, B, flags, _opt(st.options))
+        nbytes = lib.ligdiff_forward_workspace_bytes_opt(N, graph.n_edges, B, flags, eng._o(st.options))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=eng.device)   # kept alive until backward
         atom = torch.empty(N, 119, dtype=torch.float32, device=eng.device)
         posp = torch.empty(N, 3, dtype=torch.float32, device=eng.device)
@@ -38,7 +43,7 @@ class ScoreNetworkFunction(torch.autograd.Function):
             rc = lib.ligdiff_forward_opt(eng.table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.t), None,
                                          _ptr(st.props), flags, _ptr(atom), _ptr(posp), _ptr(prop), _ptr(ws),
                                          ws.numel(), _stream(), C.byref(st.dropout) if st.dropout is not None else None,
-                                         _opt(st.options))
+                                         eng._o(st.options))
         check(rc, "ligdiff_forward_train(save)")
         ctx.st, ctx.ws, ctx.flags = st, ws, flags
         st.eng.last_forward = (ws, flags) if st.keep_state else None   # for consistency() right after this call
@@ -66,18 +71,18 @@ class ScoreNetworkFunction(torch.autograd.Function):
         table = (C.c_void_p * len(eng.names))()
         gi = 0
         for i, name in enumerate(eng.names):
-            if _has_grad_slot(name):
+            if eng.present[i] and _has_grad_slot(name):
                 table[i] = grads[gi].data_ptr()
                 gi += 1
             else:
                 table[i] = None
-        nbytes = lib.ligdiff_backward_workspace_bytes_opt(N, graph.n_edges, B, _opt(st.options))
+        nbytes = lib.ligdiff_backward_workspace_bytes_opt(N, graph.n_edges, B, eng._o(st.options))
         bws = eng.workspace(nbytes)
         with torch.cuda.device(dev):
             rc = lib.ligdiff_backward_opt(eng.table, table, C.byref(graph.c), _ptr(st.x), _ptr(st.pos), _ptr(st.props),
                                           ctx.flags, _ptr(d_atom), _ptr(d_pos), _ptr(d_prop), _ptr(ctx.ws), _ptr(bws),
                                           bws.numel(), _stream(),
-                                          C.byref(st.dropout) if st.dropout is not None else None, _opt(st.options))
+                                          C.byref(st.dropout) if st.dropout is not None else None, eng._o(st.options))
         check(rc, "ligdiff_backward_train")
         ctx.ws = None
         # data parallel: the parameter gradients of one backward pass are ONE zero-padded buffer, so the
@@ -87,13 +92,13 @@ class ScoreNetworkFunction(torch.autograd.Function):
             from .parallel import allreduce_sum_
             allreduce_sum_(flat, st.grad_group)
         # the flat buffer and where each parameter's gradient sits in it: the fused optimiser step works on it directly
-        eng.last_flat = {"flat": flat, "offsets": {n: o for n, o in zip([n for n in eng.names if _has_grad_slot(n)], offs)}}
+        eng.last_flat = {"flat": flat, "offsets": {n: o for n, o in zip(_grad_names(eng), offs)}}
         # parameters that did not take part get no gradient (as autograd would report them):
         # the optimiser then leaves them alone instead of applying weight decay to them
         has_props = bool(ctx.flags & _lib.FWD_PROPERTIES)
         null_cond = bool(ctx.flags & _lib.FWD_NULL_COND)
         out = []
-        pnames = [n for n in eng.names if _has_grad_slot(n)]
+        pnames = _grad_names(eng)
         for name, gten in zip(pnames, grads):
             used = True
             if name == "property_guidance.null_embedding":
@@ -129,7 +134,7 @@ class ScoreNetworkFunction(torch.autograd.Function):
                 if props.shape != (B, 15):
                     raise ValueError("properties must be [B,15]")
         sd = dict(model.state_dict(keep_vars=True))
-        params = [sd[n] for n in eng.names if _has_grad_slot(n)]
+        params = [sd[n] for n in _grad_names(eng)]
         st = _Ctx(eng=eng, graph=graph, x=x, pos=pos, t=t, props=props, flags=flags, keep_state=keep_state, dropout=dropout,
                   grad_group=getattr(model, "grad_allreduce_group", None), options=getattr(model, "library_options", None))
         return ScoreNetworkFunction.apply(st, *params)

@@ -49,8 +49,8 @@ static int check_forward_args(const float* const* weights, const ligdiff_graph* 
   if (rc) return rc;
   if (flags & ~FWD_PUBLIC_FLAGS) return LIGDIFF_ERR_ARG;   // library-internal bits are not part of the ABI
   if (!weights || !x || !pos || (!t && !t_index_dev) || !atom_pred || !pos_pred || !workspace) return LIGDIFF_ERR_ARG;
-  for (int i = 0; i < W_COUNT; ++i)
-    if (weights[i] == nullptr) return LIGDIFF_ERR_ARG;
+  for (int i = 0; i < W_COUNT; ++i)   // slots of layers beyond the call's layer_pairs may be NULL
+    if (weights[i] == nullptr && weight_slot_layer(i) < call_layer_pairs()) return LIGDIFF_ERR_ARG;
   if (t_index_dev && !(flags & LIGDIFF_FWD_T_BROADCAST)) return LIGDIFF_ERR_ARG;
   if (workspace_bytes < ligdiff_forward_workspace_bytes(graph->n_atoms, graph->n_edges, graph->n_mols, flags))
     return LIGDIFF_ERR_WORKSPACE;
@@ -168,7 +168,13 @@ extern "C" int ligdiff_forward_state_offsets(int64_t n_atoms, int64_t n_edges, i
   if (n_atoms <= 0 || n_edges < 0 || n_mols <= 0 || !hidden_offset || !pos_offset) return LIGDIFF_ERR_ARG;
   FwdLayout L;
   fwd_layout(&L, n_atoms, n_edges, n_mols, flags);
-  *hidden_offset = L.x2[2];
+  *hidden_offset = L.x2[L.nl - 1];
   *pos_offset = L.pos_cur;
   return LIGDIFF_OK;
+}
+extern "C" int ligdiff_forward_state_offsets_opt(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int flags,
+                                                 size_t* hidden_offset, size_t* pos_offset, const ligdiff_options* options) {
+  if (check_options(options)) return LIGDIFF_ERR_ARG;
+  CallOptions scope(options);
+  return ligdiff_forward_state_offsets(n_atoms, n_edges, n_mols, flags, hidden_offset, pos_offset);
 }

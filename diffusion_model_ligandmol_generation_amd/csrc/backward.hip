@@ -16,7 +16,7 @@
 struct BwdLayout {
   size_t dxa, n256c, n256d, G;
   size_t e256a, e4;
-  size_t dmod[3], b256a, b256b, b256c, b256d, b512, b2048, b8, bhid;
+  size_t dmod[LD_MAXL], b256a, b256b, b256c, b256d, b512, b2048, b8, bhid;
   size_t wt;   // transposed weight block of the dX GEMM in flight (<= 1536 x 256 elements, fp32 or split bf16: 6 bytes each)
   size_t wt_all, wt_all_floats;   // every weight block the input-gradient GEMMs need transposed, filled by ONE launch
   size_t pool, pool_bytes;   // single-use buffers: everything a weight-gradient launch on the side stream reads
@@ -25,16 +25,16 @@ struct BwdLayout {
 // Floats of all pre-transposed weight blocks (see wt_prepare): heads 3 x 256 x 256, per attention layer FFN 2 x 256 x 1024,
 // out-projection 256 x 256, in-projection 768 x 256, adaLN 1536 x 256; per E(3) layer six 256 x 256 blocks and the
 // 128 x 256 coordinate gate; second time-MLP layer 256 x 512.
-#define WT_ALL_FLOATS (3 * 65536 + 3 * (2 * 262144 + 65536 + 196608 + 393216) + 3 * (6 * 65536 + 32768) + 131072)
+#define WT_ALL_FLOATS(nl) (3 * 65536 + (nl) * (2 * 262144 + 65536 + 196608 + 393216) + (nl) * (6 * 65536 + 32768) + 131072)
 // Bytes of the single-use pool: one buffer per use of every tensor that a weight-gradient launch reads (heads,
 // per attention layer, per E(3) layer, embeddings), each rounded like `take` below.
-static size_t bwd_pool_bytes(int64_t N, int64_t E) {
+static size_t bwd_pool_bytes(int64_t N, int64_t E, int nl) {
   const int64_t dit[] = {N * 256, N * 1024, N * 256, N * 768};
   const int64_t e3[] = {N * 256, N * 256, E * 128, E * 256, E * 256, E * 32, E * 32, E * 32, N * 512};
   const int64_t once[] = {N * 512, N * 256, N * 256};
   size_t tot = 0;
   auto add = [&](int64_t nfloats) { tot += align_up((size_t)nfloats * 4 + 16, 256); };
-  for (int l = 0; l < 3; ++l) {
+  for (int l = 0; l < nl; ++l) {
     for (int64_t n : dit) add(n);
     for (int64_t n : e3) add(n);
   }
@@ -42,19 +42,20 @@ static size_t bwd_pool_bytes(int64_t N, int64_t E) {
   return tot;
 }
 static void bwd_layout(BwdLayout* L, int64_t N, int64_t E, int32_t B) {
+  const int nl = call_layer_pairs();
   size_t off = 0;
   auto take = [&](size_t nfloats) { size_t o = off; off += align_up(nfloats * 4 + 16, 256); return o; };
   L->dxa = take(N * 256); L->n256c = take(N * 256); L->n256d = take(N * 256); L->G = take(N * 3);
   L->e256a = take(E * 256); L->e4 = take(E * 4);
-  for (int l = 0; l < 3; ++l) L->dmod[l] = take((size_t)B * 1536);
+  for (int l = 0; l < nl; ++l) L->dmod[l] = take((size_t)B * 1536);
   L->b256a = take((size_t)B * 256); L->b256b = take((size_t)B * 256); L->b256c = take((size_t)B * 256);
   L->b256d = take((size_t)B * 256); L->b512 = take((size_t)B * 512); L->b2048 = take((size_t)B * 2048);
   L->b8 = take((size_t)B * 8); L->bhid = take((size_t)B * 512);
   L->wt = take(1536 * 256 * 3 / 2);
-  L->wt_all_floats = WT_ALL_FLOATS;
+  L->wt_all_floats = WT_ALL_FLOATS(nl);
   L->wt_all = take(L->wt_all_floats);
   L->pool = off;
-  L->pool_bytes = bwd_pool_bytes(N, E);
+  L->pool_bytes = bwd_pool_bytes(N, E, nl);
   off += L->pool_bytes;
   L->total = off;
 }
@@ -318,8 +319,9 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
   if (!(flags & LIGDIFF_FWD_SAVE_FOR_BACKWARD) || (flags & LIGDIFF_FWD_T_BROADCAST)) return LIGDIFF_ERR_ARG;
   // every slot of the score network needs a gradient buffer; the frequency table and the consistency
   // module (slots from W_CONS_0 on: no loss reaches it) have none
+  const int NL = call_layer_pairs();   // E(3) layers = attention layers of this model
   for (int i = 0; i < W_CONS_0; ++i)
-    if (w[i] == nullptr || (i != W_TIME_FREQS && gr[i] == nullptr)) return LIGDIFF_ERR_ARG;
+    if (weight_slot_layer(i) < NL && (w[i] == nullptr || (i != W_TIME_FREQS && gr[i] == nullptr))) return LIGDIFF_ERR_ARG;
   const int N = (int)g->n_atoms, E = (int)g->n_edges, B = g->n_mols;
   FwdLayout F;
   fwd_layout(&F, N, E, B, flags);
@@ -342,7 +344,7 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
     size_t used = 0;
     auto add = [&](const float* W, int ldw, int K, int ncols) { (void)wt_add(W, ldw, K, ncols, base, L.wt_all_floats, &used); };
     for (int h = 0; h < 3; ++h) add(w[W_HEAD(h, HEAD_W0)], 256, 256, 256);
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < NL; ++l) {
       add(w[W_DIT(l, DIT_FF3_W)], 1024, 256, 1024);
       add(w[W_DIT(l, DIT_FF0_W)], 256, 1024, 256);
       add(w[W_DIT(l, DIT_OUT_W)], 256, 256, 256);
@@ -377,7 +379,7 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
   };
 
   // ------------------------------------------------------------------ heads (model1.py:741-746)
-  const float* x_last = A(F.x2[2]);
+  const float* x_last = A(F.x2[NL - 1]);
   float* dyh = fresh((int64_t)N * 512);
   gemm_dx<8, MUL_NONE, false>(d_atom, LD_A, N, LD_A, w[W_HEAD(0, HEAD_W3)], 256, 256, dyh, 512, nullptr, 0, s);
   hipLaunchKernelGGL(k_small_dx<3>, dim3(nb4N), dim3(256), 0, s, d_pos, w[W_HEAD(1, HEAD_W3)], dyh, 512, 256, N);
@@ -416,8 +418,8 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
 
   // ------------------------------------------------------------------ DiT layers (model1.py:279-302)
   const size_t att_lds_hpb4 = (size_t)4 * (g->max_mol_atoms <= 64 ? 64 : 128) * 130 * 4;
-  for (int l = 2; l >= 0; --l) {
-    const float* x_in = (l == 0) ? A(F.h_e3[2]) : A(F.x2[l - 1]);
+  for (int l = NL - 1; l >= 0; --l) {
+    const float* x_in = (l == 0) ? A(F.h_e3[NL - 1]) : A(F.x2[l - 1]);
     const float* mod = A(F.mod[l]);
     float* dmod = T(L.dmod[l]);
     float* t256b = fresh((int64_t)N * 256);
@@ -509,7 +511,7 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
   }
 
   // ------------------------------------------------------------------ E(3) layers (model1.py:86-114, :721-725)
-  for (int l = 2; l >= 0; --l) {
+  for (int l = NL - 1; l >= 0; --l) {
     const float* h_in = (l == 0) ? A(F.h0) : A(F.h_e3[l - 1]);
     const float* W1 = w[W_E3(l, E3_EN0_W)];
     float* dW1 = gr[W_E3(l, E3_EN0_W)];
@@ -640,7 +642,7 @@ extern "C" int ligdiff_backward_train(const float* const* w, float* const* gr, c
   // ------------------------------------------------------------------ time path (model1.py:705-706, :288)
   {
     float* dstemb = T(L.b256b);
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < NL; ++l) {
       const float* dmod = T(L.dmod[l]);
       if (l == 0)
         gemm_dx<8, MUL_NONE, false>(dmod, 1536, B, 1536, w[W_DIT(l, DIT_ADA_W)], 256, 256, dstemb, 256, nullptr, 0, s);

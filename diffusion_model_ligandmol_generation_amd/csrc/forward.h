@@ -5,18 +5,20 @@
 #include <stdint.h>
 #include "../../include/ligdiff.h"
 #include "split_cache.h"
+#include "weights.h"
 
 // Byte offsets into the forward workspace (all 256-B aligned).
 struct FwdLayout {
+  int nl;                           // E(3) layers = attention layers of the call (ligdiff_options.layer_pairs)
   int64_t Bt;                       // rows of the time tensors: 1 when t is broadcast, else B
   size_t tf, t1, temb, stemb;       // Fourier features, time-MLP hidden, t_emb, SiLU(t_emb)
-  size_t mod[3];                    // adaLN parameters [Bt,1536] per DiT layer
+  size_t mod[LD_MAXL];                    // adaLN parameters [Bt,1536] per DiT layer
   size_t pemb, pstack, pg;          // PILOT embedding, stacked encoders, pareto hidden
   size_t h0;                        // [N,256] embedding output / residual stream
   size_t xpad, wpad;                // [N,128] / [256,128] zero-extended atom features and embedding weight
   size_t pos_upd, pos_cur;          // [N,3]
-  size_t P[3], rel[3], rbf[3], a1[3], msg[3], wrel[3], agg[3], hid[3], h_e3[3];
-  size_t xn1[3], qkv[3], att[3], x1[3], xn2[3], ffh[3], x2[3];
+  size_t P[LD_MAXL], rel[LD_MAXL], rbf[LD_MAXL], a1[LD_MAXL], msg[LD_MAXL], wrel[LD_MAXL], agg[LD_MAXL], hid[LD_MAXL], h_e3[LD_MAXL];
+  size_t xn1[LD_MAXL], qkv[LD_MAXL], att[LD_MAXL], x1[LD_MAXL], xn2[LD_MAXL], ffh[LD_MAXL], x2[LD_MAXL];
   size_t mol_e0, mol_slab0;         // [B+1] int32: first edge / first slab of each molecule (REDUCE form of the edge kernel)
   size_t slab_e0, slab_cnt;         // [n_slab_cap] int32: first edge / edge count of each slab
   int64_t n_slab_cap;               // slabs the tables hold: a multiple of 4 >= E / 32 + B
@@ -25,8 +27,8 @@ struct FwdLayout {
   // kept only with LIGDIFF_FWD_SAVE_FOR_BACKWARD (pre-activations the backward pass needs)
   int save;
   size_t t1_pre, ua, pen_pre, pg_pre, pz, pw;
-  size_t pre_e[3], u_m[3], hc_pre[3], cw[3], dist[3], r1pre[3], hid_pre[3], u_h[3];
-  size_t oproj[3], fproj[3], ffh_pre[3], lse[3], u_head, u_ph;
+  size_t pre_e[LD_MAXL], u_m[LD_MAXL], hc_pre[LD_MAXL], cw[LD_MAXL], dist[LD_MAXL], r1pre[LD_MAXL], hid_pre[LD_MAXL], u_h[LD_MAXL];
+  size_t oproj[LD_MAXL], fproj[LD_MAXL], ffh_pre[LD_MAXL], lse[LD_MAXL], u_head, u_ph;
   size_t wsplit, wsplit_bytes;      // split-bf16 copies of the GEMM weights (split-operand mode only, else 0 bytes)
   size_t total;
 };
@@ -73,10 +75,10 @@ struct FwdProbe { const char* label; hipEvent_t e0, e1; int hits; };
 int check_graph(const ligdiff_graph* g);
 
 // Time embedding + adaLN parameters for n_rows timesteps t[0..n_rows) with the kernels (and the
-// per-row summation order) of the shared-timestep path: temb [n,256], mod_l [n,1536];
+// per-row summation order) of the shared-timestep path: temb [n,256], mods[l] [n,1536] for l < n_layers;
 // tf [n,256], t1 [n,512], stemb [n,256] are scratch.
 int run_time_rows(const float* const* w, const float* t, int n_rows, float* tf, float* t1, float* temb,
-                  float* stemb, float* mod0, float* mod1, float* mod2, hipStream_t s);
+                  float* stemb, float* const* mods, int n_layers, hipStream_t s);
 
 int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, const float* pos,
                 const float* t, const int32_t* t_index_dev, const float* properties, int flags,

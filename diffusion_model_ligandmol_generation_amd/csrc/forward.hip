@@ -43,7 +43,7 @@ const WeightInfo* weight_table() {
       wt_set(t, W_PENC(i, 2), 256 * 64, "property_guidance.property_encoders.%d.2.weight", i);
       wt_set(t, W_PENC(i, 3), 256, "property_guidance.property_encoders.%d.2.bias", i);
     }
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < LD_MAXL; ++l) {
       wt_set(t, W_E3(l, E3_RB0_W), 32, "equivariant_layers.%d.radial_basis.0.weight", l);
       wt_set(t, W_E3(l, E3_RB0_B), 32, "equivariant_layers.%d.radial_basis.0.bias", l);
       wt_set(t, W_E3(l, E3_RB2_W), 32 * 32, "equivariant_layers.%d.radial_basis.2.weight", l);
@@ -65,7 +65,7 @@ const WeightInfo* weight_table() {
       wt_set(t, W_E3(l, E3_CN2_W), 128, "equivariant_layers.%d.coord_network.2.weight", l);
       wt_set(t, W_E3(l, E3_CN2_B), 1, "equivariant_layers.%d.coord_network.2.bias", l);
     }
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < LD_MAXL; ++l) {
       wt_set(t, W_DIT(l, DIT_ADA_W), 1536 * 256, "dit_layers.%d.adaLN_modulation.1.weight", l);
       wt_set(t, W_DIT(l, DIT_ADA_B), 1536, "dit_layers.%d.adaLN_modulation.1.bias", l);
       wt_set(t, W_DIT(l, DIT_INP_W), 768 * 256, "dit_layers.%d.attention.in_proj_weight", l);
@@ -126,12 +126,15 @@ extern "C" void ligdiff_options_init(ligdiff_options* o) {
   if (o == nullptr) return;
   o->gemm_mode = -1; o->chain_mode = -1; o->concurrent_calls = 0;
   o->edge_chain = -1; o->node_chain = -1; o->mol_wave = -1; o->edge_reduce = -1; o->cfg_two_pass = -1;
+  o->layer_pairs = -1;
 }
+int call_layer_pairs() { return (t_options != nullptr && t_options->layer_pairs > 0) ? t_options->layer_pairs : 3; }
 int check_options(const ligdiff_options* o) {
   if (o == nullptr) return LIGDIFF_OK;
   auto tri = [](int v) { return v >= -1 && v <= 1; };
   if (!tri(o->gemm_mode) || o->chain_mode < -1 || o->chain_mode > 2 || o->concurrent_calls < 0 || o->concurrent_calls > 16 ||
-      !tri(o->edge_chain) || !tri(o->node_chain) || !tri(o->mol_wave) || !tri(o->edge_reduce) || !tri(o->cfg_two_pass))
+      !tri(o->edge_chain) || !tri(o->node_chain) || !tri(o->mol_wave) || !tri(o->edge_reduce) || !tri(o->cfg_two_pass) ||
+      o->layer_pairs < -1 || o->layer_pairs > LD_MAXL)
     return LIGDIFF_ERR_ARG;
   return LIGDIFF_OK;
 }
@@ -216,13 +219,11 @@ extern "C" int ligdiff_plan(int64_t n_atoms, int64_t n_edges, int32_t n_mols, in
 }
 // Bytes reserved for the split weight copies: 6 bytes per weight element plus room for blocks whose
 // rows are zero-extended to the 128 / 256 columns of a block (a full region falls back to the fp32 pipe).
-static size_t split_region_bytes() {
-  static const size_t bytes = [] {
-    size_t elems = 0;
-    for (int i = 0; i < W_CONS_0; ++i) elems += (size_t)weight_table()[i].numel;
-    return align_up(elems * 6 + elems * 6 / 4 + (2u << 20), 256);
-  }();
-  return bytes;
+static size_t split_region_bytes(int nl) {
+  size_t elems = 0;
+  for (int i = 0; i < W_CONS_0; ++i)
+    if (weight_slot_layer(i) < nl) elems += (size_t)weight_table()[i].numel;
+  return align_up(elems * 6 + elems * 6 / 4 + (2u << 20), 256);
 }
 
 // ------------------------------------------------------------------ dropout sites
@@ -237,7 +238,9 @@ bool make_drop_site(const ligdiff_dropout* d, int layer, int kind, DropSite* out
   if (p == 0.0f) return true;
   out->seed = d->seed;
   out->row_offset = kind == LIGDIFF_DROP_CONS_BOND ? 0 : d->atom_offset;   // pairs are numbered per call
-  out->site = kind >= LIGDIFF_DROP_CONS_ATOM ? (uint32_t)(12 + kind) : (uint32_t)(layer * 4 + kind);
+  // sites 0..11: layers 0..2; 15, 16: the consistency module; layers 3.. follow from 32 on
+  out->site = kind >= LIGDIFF_DROP_CONS_ATOM ? (uint32_t)(12 + kind)
+              : layer < 3 ? (uint32_t)(layer * 4 + kind) : (uint32_t)(32 + layer * 4 + kind);
   const double t = (double)p * 4294967296.0;
   out->thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
   if (out->thr == 0u) out->thr = 1u;
@@ -248,7 +251,7 @@ int check_dropout(const ligdiff_dropout* d) {
   if (d == nullptr) return LIGDIFF_OK;
   if (d->atom_offset < 0) return LIGDIFF_ERR_ARG;
   bool any = false;
-  for (int l = 0; l < 3; ++l)
+  for (int l = 0; l < call_layer_pairs(); ++l)
     for (int k = 0; k < 3; ++k) {
       DropSite ds;
       if (!make_drop_site(d, l, k, &ds)) return LIGDIFF_ERR_ARG;
@@ -280,7 +283,7 @@ __global__ void k_dropout_mask(DropSite d, int kind, int64_t n_atoms, float* __r
 }
 extern "C" int ligdiff_dropout_mask(const ligdiff_dropout* dropout, int32_t layer, int32_t kind, int64_t n_atoms,
                                     float* out, void* stream) {
-  if (!dropout || layer < 0 || layer > 2 || kind < 0 || kind > LIGDIFF_DROP_CONS_BOND || n_atoms <= 0 || !out ||
+  if (!dropout || layer < 0 || layer >= LD_MAXL || kind < 0 || kind > LIGDIFF_DROP_CONS_BOND || n_atoms <= 0 || !out ||
       n_atoms >= (1LL << 30))
     return LIGDIFF_ERR_ARG;
   DropSite ds;
@@ -298,11 +301,13 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
   const bool bcast = (flags & LIGDIFF_FWD_T_BROADCAST) != 0;
   const bool save = (flags & LIGDIFF_FWD_SAVE_FOR_BACKWARD) != 0;
   const int64_t Bt = bcast ? 1 : B;
+  const int nl = call_layer_pairs();
+  L->nl = nl;
   size_t off = 0;
   auto take = [&](size_t nfloats) { size_t o = off; off += align_up(nfloats * 4, 256); return o; };
   L->Bt = Bt;
   L->tf = take(Bt * 256); L->t1 = take(Bt * 512); L->temb = take(Bt * 256); L->stemb = take(Bt * 256);
-  for (int l = 0; l < 3; ++l) L->mod[l] = take(Bt * 1536);
+  for (int l = 0; l < nl; ++l) L->mod[l] = take(Bt * 1536);
   L->pemb = take((size_t)B * 256); L->pstack = take((size_t)B * 2048); L->pg = take((size_t)B * 256);
   L->h0 = take(N * 256);
   L->xpad = take(N * 128); L->wpad = take(256 * 128);
@@ -310,10 +315,10 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
   // Without SAVE every layer reuses layer 0's scratch and the residual stream is updated
   // in place (each element is read and rewritten by the same thread of the epilogue).
   auto per_layer = [&](size_t* arr, size_t nfloats) {
-    for (int l = 0; l < 3; ++l) arr[l] = (save || l == 0) ? take(nfloats) : arr[0];
+    for (int l = 0; l < nl; ++l) arr[l] = (save || l == 0) ? take(nfloats) : arr[0];
   };
   auto stream_buf = [&](size_t* arr) {
-    for (int l = 0; l < 3; ++l) arr[l] = save ? take(N * 256) : L->h0;
+    for (int l = 0; l < nl; ++l) arr[l] = save ? take(N * 256) : L->h0;
   };
   per_layer(L->P, N * 512); per_layer(L->rel, E * 4); per_layer(L->rbf, E * 32);
   per_layer(L->a1, E * 256); per_layer(L->msg, E * 256); per_layer(L->wrel, E * 4);
@@ -331,7 +336,7 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
     L->t1_pre = take(Bt * 512); L->ua = take(N * 256);
     L->pen_pre = take((size_t)B * 512); L->pg_pre = take((size_t)B * 256);
     L->pz = take((size_t)B * 8); L->pw = take((size_t)B * 8);
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < nl; ++l) {
       L->pre_e[l] = take(E * 256); L->u_m[l] = take(E * 256); L->hc_pre[l] = take(E * 128);
       L->cw[l] = take(E); L->dist[l] = take(E); L->r1pre[l] = take(E * 32);
       L->hid_pre[l] = take(N * 256); L->u_h[l] = take(N * 256);
@@ -341,24 +346,24 @@ void fwd_layout(FwdLayout* L, int64_t N, int64_t E, int32_t B, int flags) {
     L->u_head = take(N * 512); L->u_ph = take((size_t)B * 256);
   }
   L->wsplit = off;
-  L->wsplit_bytes = split_gemm_enabled() ? split_region_bytes() : 0;
+  L->wsplit_bytes = split_gemm_enabled() ? split_region_bytes(nl) : 0;
   off += L->wsplit_bytes;
   L->total = off;
 }
 
 // ------------------------------------------------------------------ time path for a table of timesteps
 int run_time_rows(const float* const* w, const float* t, int n_rows, float* tf, float* t1, float* temb,
-                  float* stemb, float* mod0, float* mod1, float* mod2, hipStream_t s) {
-  if (n_rows <= 0) return LIGDIFF_ERR_ARG;
+                  float* stemb, float* const* mods, int n_layers, hipStream_t s) {
+  if (n_rows <= 0 || n_layers <= 0 || n_layers > LD_MAXL) return LIGDIFF_ERR_ARG;
   hipLaunchKernelGGL(k_fourier, dim3(n_rows), dim3(128), 0, s, t, (const int32_t*)nullptr, w[W_TIME_FREQS], tf);
   SmallLinearSets p0 = {{w[W_T0_W]}, {w[W_T0_B]}, {t1}};
   hipLaunchKernelGGL((k_small_linear<1, false>), dim3(128, 1), dim3(256), 0, s, tf, p0, (float*)nullptr, n_rows, 256, 512);
   SmallLinearSets p2 = {{w[W_T2_W]}, {w[W_T2_B]}, {temb}};
   hipLaunchKernelGGL((k_small_linear<0, true>), dim3(64, 1), dim3(256), 0, s, t1, p2, stemb, n_rows, 512, 256);
   SmallLinearSets pa;
-  float* mods[3] = {mod0, mod1, mod2};
-  for (int l = 0; l < 3; ++l) { pa.W[l] = w[W_DIT(l, DIT_ADA_W)]; pa.b[l] = w[W_DIT(l, DIT_ADA_B)]; pa.C[l] = mods[l]; }
-  hipLaunchKernelGGL((k_small_linear<0, false>), dim3(384, 3), dim3(256), 0, s, stemb, pa, (float*)nullptr, n_rows, 256, 1536);
+  memset(&pa, 0, sizeof pa);
+  for (int l = 0; l < n_layers; ++l) { pa.W[l] = w[W_DIT(l, DIT_ADA_W)]; pa.b[l] = w[W_DIT(l, DIT_ADA_B)]; pa.C[l] = mods[l]; }
+  hipLaunchKernelGGL((k_small_linear<0, false>), dim3(384, n_layers), dim3(256), 0, s, stemb, pa, (float*)nullptr, n_rows, 256, 1536);
   LD_CHECK_LAUNCH();
   return LIGDIFF_OK;
 }
@@ -383,6 +388,9 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   };
   FwdLayout L;
   fwd_layout(&L, N, E, B, flags);
+  const int NL = L.nl;   // E(3) layers = attention layers of this model
+  for (int i = 0; i < W_CONS_0; ++i)
+    if (weight_slot_layer(i) < NL && w[i] == nullptr) return LIGDIFF_ERR_ARG;
   // split-operand mode: the caller's cache (kept over the calls of one sampling loop) or one for this call
   SplitCache local_split;
   struct SplitScope {
@@ -418,9 +426,10 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     hipLaunchKernelGGL((k_small_linear<0, true>), dim3(64, 1), dim3(256), 0, s, F(L.t1), p2, F(L.stemb), Bt, 512, 256);
     PE();
     SmallLinearSets pa;
-    for (int l = 0; l < 3; ++l) { pa.W[l] = w[W_DIT(l, DIT_ADA_W)]; pa.b[l] = w[W_DIT(l, DIT_ADA_B)]; pa.C[l] = F(L.mod[l]); }
+    memset(&pa, 0, sizeof pa);
+    for (int l = 0; l < NL; ++l) { pa.W[l] = w[W_DIT(l, DIT_ADA_W)]; pa.b[l] = w[W_DIT(l, DIT_ADA_B)]; pa.C[l] = F(L.mod[l]); }
     PB("dit.adaln");
-    hipLaunchKernelGGL((k_small_linear<0, false>), dim3(384, 3), dim3(256), 0, s, F(L.stemb), pa, (float*)nullptr, Bt, 256, 1536);
+    hipLaunchKernelGGL((k_small_linear<0, false>), dim3(384, NL), dim3(256), 0, s, F(L.stemb), pa, (float*)nullptr, Bt, 256, 1536);
     PE();
   } else {
     PB("time.fourier");
@@ -433,7 +442,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     PB("time.mlp2");
     gemm_bias_act<ACT_NONE, true>(F(L.t1), 512, Bt, 512, w[W_T2_W], 512, w[W_T2_B], 1, F(L.temb), 256, F(L.stemb), s);
     PE();
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < NL; ++l) {
       PB("dit%d.adaln", l);
       gemm_bias_act<ACT_NONE, false>(F(L.stemb), 256, Bt, 256, w[W_DIT(l, DIT_ADA_W)], 256, w[W_DIT(l, DIT_ADA_B)], 6,
                                      F(L.mod[l]), 1536, nullptr, s);
@@ -522,13 +531,13 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
   int32_t* const mol_slab0 = reinterpret_cast<int32_t*>(ws + L.mol_slab0);
   int32_t* const slab_e0 = reinterpret_cast<int32_t*>(ws + L.slab_e0);
   int32_t* const slab_cnt = reinterpret_cast<int32_t*>(ws + L.slab_cnt);
-  if (edge_reduce) {   // molecule-aligned 32-edge slabs, the same for the three layers
+  if (edge_reduce) {   // molecule-aligned 32-edge slabs, the same for every layer
     const int cap = (int)L.n_slab_cap;
     hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(1024), 0, s, g->mol_ptr, g->dst_ptr, B, mol_e0, mol_slab0);
     hipLaunchKernelGGL(k_slab_fill, dim3(ceil_div(B, 4) + ceil_div(cap, 256)), dim3(256), 0, s, mol_e0, mol_slab0, B, cap,
                        slab_e0, slab_cnt);
   }
-  for (int l = 0; l < 3; ++l) {
+  for (int l = 0; l < NL; ++l) {
     const float* pos_l = (l == 0) ? pos : F(L.pos_cur);
     // per-node halves of the first edge linear: P = h [W1a | W1b]^T
     if (!node_chain || l == 0) {
@@ -627,7 +636,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       na.Wn1 = w[W_E3(l, E3_NN0_W)]; na.b1 = w[W_E3(l, E3_NN0_B)]; na.Wn2 = w[W_E3(l, E3_NN2_W)]; na.b2 = w[W_E3(l, E3_NN2_B)];
       na.gamma = w[W_E3(l, E3_NN3_G)]; na.beta = w[W_E3(l, E3_NN3_B)];
       PB("e3_%d.node_chain", l);
-      if (l < 2) {
+      if (l < NL - 1) {
         na.Wt = w[W_E3(l + 1, E3_EN0_W)]; na.bt = edge_chain ? w[W_E3(l + 1, E3_EN0_B)] : nullptr; na.tout = F(L.P[l + 1]);
         launch_node_chain(na, NODE_TAIL_PROJ, s);
       } else if (dit_chain && !mol_wave) {
@@ -680,7 +689,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
                        g->atom_mol, F(L.xn1[0]), N);
     PE();
   }
-  for (int l = 0; l < 3; ++l) {
+  for (int l = 0; l < NL; ++l) {
     if (!dit_chain) {
       PB("dit%d.qkv", l);
       gemm_bias_act<ACT_NONE, false>(F(L.xn1[l]), 256, N, 256, w[W_DIT(l, DIT_INP_W)], 256, w[W_DIT(l, DIT_INP_B)], 3,
@@ -734,7 +743,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       da.Wo = w[W_DIT(l, DIT_OUT_W)]; da.bo = w[W_DIT(l, DIT_OUT_B)];
       da.W1 = w[W_DIT(l, DIT_FF0_W)]; da.b1 = w[W_DIT(l, DIT_FF0_B)]; da.W2 = w[W_DIT(l, DIT_FF3_W)]; da.b2 = w[W_DIT(l, DIT_FF3_B)];
       da.mod = F(L.mod[l]);
-      if (l < 2) {
+      if (l < NL - 1) {
         da.mod_next = F(L.mod[l + 1]); da.Wqkv = w[W_DIT(l + 1, DIT_INP_W)]; da.bqkv = w[W_DIT(l + 1, DIT_INP_B)];
         da.qkv = F(L.qkv[l + 1]);
       }
@@ -742,7 +751,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         da.Wqkv_self = w[W_DIT(l, DIT_INP_W)]; da.bqkv_self = w[W_DIT(l, DIT_INP_B)]; da.mol_ptr = g->mol_ptr; da.B = B;
         da.Wqkv = nullptr; da.bqkv = nullptr; da.qkv = nullptr; da.mod_next = nullptr;
       }
-      if (l == 2) {   // the last layer carries the atom and coordinate heads (model1.py:741-742)
+      if (l == NL - 1) {   // the last layer carries the atom and coordinate heads (model1.py:741-742)
         da.W0a = w[W_HEAD(0, HEAD_W0)]; da.b0a = w[W_HEAD(0, HEAD_B0)]; da.ga = w[W_HEAD(0, HEAD_G)]; da.bea = w[W_HEAD(0, HEAD_BE)];
         da.W3a = w[W_HEAD(0, HEAD_W3)]; da.b3a = w[W_HEAD(0, HEAD_B3)];
         da.W0p = w[W_HEAD(1, HEAD_W0)]; da.b0p = w[W_HEAD(1, HEAD_B0)]; da.gp = w[W_HEAD(1, HEAD_G)]; da.bep = w[W_HEAD(1, HEAD_BE)];
@@ -750,7 +759,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         da.pos_upd = F(L.pos_upd); da.atom_pred = atom_pred; da.pos_pred = pos_pred;
       }
       PB("dit%d.chain", l);
-      launch_dit_chain(da, l == 2 ? DIT_TAIL_HEADS : mol_wave ? DIT_TAIL_NONE : DIT_TAIL_QKV, mol_wave, s);
+      launch_dit_chain(da, l == NL - 1 ? DIT_TAIL_HEADS : mol_wave ? DIT_TAIL_NONE : DIT_TAIL_QKV, mol_wave, s);
       PE();
       x_in = F(L.x2[l]);
       continue;
@@ -783,7 +792,7 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
     PE();
     {  // x2 = x1 + gate_mlp * (ffh W3^T + b); next layer's xn1 fused
       GemmCore gc = core_blocks(N, 1024, 256, w[W_DIT(l, DIT_FF3_W)], 1024, 1, 256);
-      if (l < 2) {
+      if (l < NL - 1) {
         PB("dit%d.ffn_down", l);
         if (dout.thr != 0u) {   // Dropout on the FFN output before the gated residual, model1.py:271-272
           EpiGate<true, true> e{N, w[W_DIT(l, DIT_FF3_B)], F(L.x1[l]), F(L.mod[l]), mstride, 1280, F(L.mod[l + 1]), 0, 256,

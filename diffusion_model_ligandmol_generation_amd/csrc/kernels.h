@@ -3,6 +3,7 @@
 // one destination node or one (molecule, head) so that every global access is a
 // contiguous 128-B..1-KiB segment.
 #pragma once
+#include "weights.h"
 #include "common.h"
 
 // accumulator row of register r in lane half h of a 32x32 MFMA tile
@@ -23,7 +24,7 @@ __global__ void k_fourier(const float* __restrict__ t, const int32_t* __restrict
 // M = 1): one wave per output feature, k split over the lanes.  A 128-row MFMA tile would
 // run one workgroup for the whole layer; this spreads the weight read over the chip.
 //   C[m, o] = act(A[m,:] . W[o,:] + b[o]),  optional C2 = SiLU(C).  blockIdx.y picks a set.
-struct SmallLinearSets { const float* W[3]; const float* b[3]; float* C[3]; };
+struct SmallLinearSets { const float* W[LD_MAXL]; const float* b[LD_MAXL]; float* C[LD_MAXL]; };
 template <int ACT, bool DUAL_SILU>
 __global__ __launch_bounds__(256) void k_small_linear(const float* __restrict__ A, SmallLinearSets p,
                                                       float* __restrict__ C2, int M, int K, int Nout) {

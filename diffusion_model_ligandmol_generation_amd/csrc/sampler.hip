@@ -247,7 +247,7 @@ extern "C" int ligdiff_ddim_step(const ligdiff_step_args* a, int32_t t_cur, int3
 // alone leave most GEMMs at one workgroup per CU.  Molecules never interact, so the result equals two
 // separate passes bit for bit.  LIGDIFF_CFG_TWO_PASS=1 keeps the two-pass form (A/B switch used by the tests).
 struct SampleLayout {
-  size_t fwd, eps_x, eps_pos, eps_xu, eps_pu, t_index, tvals, tf, t1, stemb, tab_temb, tab_mod[3];
+  size_t fwd, eps_x, eps_pos, eps_xu, eps_pu, t_index, tvals, tf, t1, stemb, tab_temb, tab_mod[LD_MAXL];
   // doubled batch of the one-pass guided form: state copies and the int32 arrays of its ligdiff_graph
   size_t x2, pos2, g_mol_ptr, g_atom_mol, g_dst_ptr, g_src_ptr, g_src, g_dst, g_src_slot;
   size_t total;
@@ -278,7 +278,7 @@ static void sample_layout(SampleLayout* L, int64_t N, int64_t E, int32_t B, int 
   const size_t T = (size_t)(n_steps > 0 ? n_steps : 1);
   L->tvals = take(T * 4); L->tf = take(T * 256 * 4); L->t1 = take(T * 512 * 4); L->stemb = take(T * 256 * 4);
   L->tab_temb = take(T * 256 * 4);
-  for (int l = 0; l < 3; ++l) L->tab_mod[l] = take(T * 1536 * 4);
+  for (int l = 0; l < F.nl; ++l) L->tab_mod[l] = take(T * 1536 * 4);
   L->total = off;
 }
 
@@ -298,10 +298,10 @@ __global__ void k_iota_float(float* v, int n) {
 // (1216 float4), then counter[1] = r (index of the step now in progress, read by its update
 // kernel) and counter[0] = r + delta (the next one).  A single workgroup so that the counter can be
 // advanced after its barrier: every thread has read counter[0] by then.
-struct TimeGatherArgs { const float* tab_temb; const float* tab_mod[3]; float* temb; float* mod[3]; };
+struct TimeGatherArgs { const float* tab_temb; const float* tab_mod[LD_MAXL]; float* temb; float* mod[LD_MAXL]; int n_layers; };
 __global__ __launch_bounds__(1024) void k_step_prologue(int32_t* counter, TimeGatherArgs p, int delta) {
   const int t = counter[0];
-  for (int i = threadIdx.x; i < 64 + 3 * 384; i += 1024) {
+  for (int i = threadIdx.x; i < 64 + p.n_layers * 384; i += 1024) {
     if (i < 64) {
       reinterpret_cast<f32x4*>(p.temb)[i] = reinterpret_cast<const f32x4*>(p.tab_temb + (size_t)t * 256)[i];
     } else {
@@ -429,8 +429,10 @@ static int sample_loop(const float* const* weights, const ligdiff_graph* graph, 
     hipLaunchKernelGGL(k_int_to_float, dim3(ceil_div(n_steps, 256)), dim3(256), 0, s, ddim_ts, WF(L.tvals), n_steps);
   else
     hipLaunchKernelGGL(k_iota_float, dim3(ceil_div(n_steps, 256)), dim3(256), 0, s, WF(L.tvals), n_steps);
-  int rc = run_time_rows(weights, WF(L.tvals), n_steps, WF(L.tf), WF(L.t1), WF(L.tab_temb), WF(L.stemb),
-                         WF(L.tab_mod[0]), WF(L.tab_mod[1]), WF(L.tab_mod[2]), s);
+  const int NL = call_layer_pairs();
+  float* tab_mods[LD_MAXL];
+  for (int l = 0; l < NL; ++l) tab_mods[l] = WF(L.tab_mod[l]);
+  int rc = run_time_rows(weights, WF(L.tvals), n_steps, WF(L.tf), WF(L.t1), WF(L.tab_temb), WF(L.stemb), tab_mods, NL, s);
   if (rc) return rc;
   const bool one_pass = guided && cfg_one_pass();
   const int64_t N1 = graph->n_atoms, E1 = graph->n_edges;
@@ -451,8 +453,9 @@ static int sample_loop(const float* const* weights, const ligdiff_graph* graph, 
   FwdLayout FL;
   fwd_layout(&FL, graph2.n_atoms, graph2.n_edges, graph2.n_mols, LIGDIFF_FWD_T_BROADCAST);
   TimeGatherArgs tg;
-  tg.tab_temb = WF(L.tab_temb); tg.temb = WF(L.fwd + FL.temb);
-  for (int l = 0; l < 3; ++l) { tg.tab_mod[l] = WF(L.tab_mod[l]); tg.mod[l] = WF(L.fwd + FL.mod[l]); }
+  memset(&tg, 0, sizeof tg);
+  tg.tab_temb = WF(L.tab_temb); tg.temb = WF(L.fwd + FL.temb); tg.n_layers = NL;
+  for (int l = 0; l < NL; ++l) { tg.tab_mod[l] = WF(L.tab_mod[l]); tg.mod[l] = WF(L.fwd + FL.mod[l]); }
 
   ligdiff_step_args a;
   memset(&a, 0, sizeof a);

@@ -6,6 +6,7 @@ entry points on the current HIP stream.
 """
 import ctypes as C
 import math
+import re
 import threading
 
 import torch
@@ -105,9 +106,22 @@ class ScoreNetworkEngine:
         self.freqs = time_frequencies(model.hidden_dim).to(self.device)
         n = self.lib.ligdiff_weight_count()
         self.names = [self.lib.ligdiff_weight_name(i).decode() for i in range(n)]
+        # E(3) layers = attention layers = num_layers // 2 (model1.py:627-634); the table has slots for
+        # _lib.MAX_LAYER_PAIRS of each, those of layers the model does not have stay NULL
+        self.layer_pairs = len(model.dit_layers)
+        if len(model.equivariant_layers) != self.layer_pairs or not 1 <= self.layer_pairs <= _lib.MAX_LAYER_PAIRS:
+            raise RuntimeError("the HIP library runs 1..8 E(3) layers and as many attention layers")
+        self.present = []
         self.table = (C.c_void_p * n)()
         self._sig = []
         for i, name in enumerate(self.names):
+            m = re.match(r"(equivariant_layers|dit_layers)\.(\d+)\.", name)
+            if m and int(m.group(2)) >= self.layer_pairs:
+                self.present.append(False)
+                self.table[i] = None
+                self._sig.append(None)
+                continue
+            self.present.append(True)
             t = self.freqs if name == "__time_freqs__" else params[name]
             if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
                 raise RuntimeError(f"weight {name} must be a contiguous fp32 tensor on {self.device}")
@@ -115,6 +129,7 @@ class ScoreNetworkEngine:
                 raise RuntimeError(f"weight {name} has {t.numel()} elements, expected {self.lib.ligdiff_weight_numel(i)}")
             self.table[i] = t.data_ptr()
             self._sig.append(t.data_ptr())
+        self.live_names = [nm for nm, ok in zip(self.names, self.present) if ok]   # slots this model fills
         self._params = params
         self._tls = threading.local()   # workspace cache and side stream of the calling thread
         self.max_atoms = model.max_atoms
@@ -122,9 +137,18 @@ class ScoreNetworkEngine:
     def stale(self, model):
         sd = model.state_dict(keep_vars=True)
         for i, name in enumerate(self.names):
-            if name != "__time_freqs__" and sd[name].data_ptr() != self._sig[i]:
+            if self.present[i] and name != "__time_freqs__" and sd[name].data_ptr() != self._sig[i]:
                 return True
         return False
+
+    def _o(self, options):
+        """ctypes argument for a call's options: the caller's struct with this model's layer count filled in
+        (None, i.e. the library defaults, for a six-layer model without options)."""
+        if self.layer_pairs == 3 and (options is None or options.layer_pairs in (-1, 0, 3)):
+            return _opt(options)
+        o = options.copy() if options is not None else Options()
+        o.layer_pairs = self.layer_pairs
+        return C.byref(o)
 
     def set_split_gemm(self, enabled):
         """Switch the library's forward GEMMs between the fp32 matrix pipe (False, default) and the
@@ -134,7 +158,7 @@ class ScoreNetworkEngine:
 
     def ddpm_workspace_bytes(self, graph, guided, n_steps, options=None):
         return int(self.lib.ligdiff_ddpm_sample_workspace_bytes_opt(graph.n_atoms, graph.n_edges, graph.n_mols,
-                                                                    1 if guided else 0, int(n_steps), _opt(options)))
+                                                                    1 if guided else 0, int(n_steps), self._o(options)))
 
     @staticmethod
     def options(**fields):
@@ -155,7 +179,7 @@ class ScoreNetworkEngine:
         Fields that ``options`` already sets are kept."""
         out = Options()
         with torch.cuda.device(self.device):
-            check(self.lib.ligdiff_plan(int(n_atoms), int(n_edges), int(n_mols), int(max_mol_atoms), _opt(options),
+            check(self.lib.ligdiff_plan(int(n_atoms), int(n_edges), int(n_mols), int(max_mol_atoms), self._o(options),
                                         C.byref(out)), "ligdiff_plan")
         return out
 
@@ -227,7 +251,7 @@ class ScoreNetworkEngine:
             flags |= _lib.FWD_SKIP_PROP_HEAD
         if save:
             flags |= _lib.FWD_SAVE_FOR_BACKWARD
-        nbytes = self.lib.ligdiff_forward_workspace_bytes_opt(N, graph.n_edges, B, flags, _opt(options))
+        nbytes = self.lib.ligdiff_forward_workspace_bytes_opt(N, graph.n_edges, B, flags, self._o(options))
         ws = workspace if workspace is not None else self.workspace(nbytes)
         atom_pred = torch.empty(N, 119, dtype=torch.float32, device=self.device)
         pos_pred = torch.empty(N, 3, dtype=torch.float32, device=self.device)
@@ -237,7 +261,7 @@ class ScoreNetworkEngine:
                                               _ptr(properties) if (properties is not None and not null_cond) else None,
                                               flags, _ptr(atom_pred), _ptr(pos_pred), _ptr(prop_pred), _ptr(ws),
                                               ws.numel(), _stream(),
-                                              C.byref(dropout) if dropout is not None else None, _opt(options))
+                                              C.byref(dropout) if dropout is not None else None, self._o(options))
         check(rc, "ligdiff_forward")
         self.last_forward = (ws, flags) if keep_state else None   # for consistency() right after this call
         return atom_pred, pos_pred, prop_pred
@@ -253,7 +277,7 @@ class ScoreNetworkEngine:
         """Mean duration in ms (HIP events on the launch stream) of one labelled launch of
         the forward pass in situ; measurement hook used by bench.py."""
         flags = _lib.FWD_T_BROADCAST | _lib.FWD_SKIP_PROP_HEAD
-        nbytes = self.lib.ligdiff_forward_workspace_bytes_opt(graph.n_atoms, graph.n_edges, graph.n_mols, flags, _opt(options))
+        nbytes = self.lib.ligdiff_forward_workspace_bytes_opt(graph.n_atoms, graph.n_edges, graph.n_mols, flags, self._o(options))
         ws = self.workspace(nbytes)
         a = torch.empty(graph.n_atoms, 119, dtype=torch.float32, device=self.device)
         p = torch.empty(graph.n_atoms, 3, dtype=torch.float32, device=self.device)
@@ -261,7 +285,7 @@ class ScoreNetworkEngine:
         with torch.cuda.device(self.device):
             rc = self.lib.ligdiff_forward_timed_opt(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), None, _ptr(t_index),
                                                     None, flags, _ptr(a), _ptr(p), None, _ptr(ws), ws.numel(), _stream(),
-                                                    label.encode(), int(reps), C.byref(ms), _opt(options))
+                                                    label.encode(), int(reps), C.byref(ms), self._o(options))
         check(rc, f"ligdiff_forward_timed({label})")
         return float(ms.value)
 
@@ -328,7 +352,7 @@ class ScoreNetworkEngine:
         with torch.cuda.device(self.device):
             check(self.lib.ligdiff_ddim_step(C.byref(args), int(t_cur), int(t_next), _stream()), "ligdiff_ddim_step")
 
-    def consistency(self, graph, ws, flags, dropout=None):
+    def consistency(self, graph, ws, flags, dropout=None, options=None):
         """MolDiff consistency outputs (model1.py:750-753) from the state a forward call left in
         its workspace ``ws`` (called with ``flags``).  Returns the reference's 4-tuple
         (atom_logits [N,119], bond_logits [P,5] or None, valency_constrained [N,N],
@@ -336,8 +360,8 @@ class ScoreNetworkEngine:
         lib, dev = self.lib, self.device
         N, B = graph.n_atoms, graph.n_mols
         h_off, p_off = C.c_size_t(0), C.c_size_t(0)
-        check(lib.ligdiff_forward_state_offsets(N, graph.n_edges, B, int(flags), C.byref(h_off), C.byref(p_off)),
-              "ligdiff_forward_state_offsets")
+        check(lib.ligdiff_forward_state_offsets_opt(N, graph.n_edges, B, int(flags), C.byref(h_off), C.byref(p_off),
+                                                    self._o(options)), "ligdiff_forward_state_offsets")
         sizes = (graph.mol_ptr[1:] - graph.mol_ptr[:-1]).to(torch.int64)
         pair_ptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
         pair_ptr[1:] = torch.cumsum(sizes * (sizes - 1), 0)
@@ -377,7 +401,7 @@ class ScoreNetworkEngine:
         self._check_sizes(graph)
         guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
         nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes_opt(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
-                                                                  int(n_steps), _opt(options))
+                                                                  int(n_steps), self._o(options))
         if workspace is not None and workspace.numel() < nbytes:
             raise ValueError("workspace too small")
         ws = self.workspace(nbytes) if workspace is None else workspace
@@ -389,7 +413,7 @@ class ScoreNetworkEngine:
                                                       float(guidance_scale), float(temperature), _ptr(model.betas),
                                                       _ptr(model.alphas), _ptr(model.alphas_cumprod), int(n_steps),
                                                       int(seed), int(atom_offset), 1 if use_graph else 0, _ptr(ws),
-                                                      ws.numel(), C.c_void_p(stream.cuda_stream), _opt(options))
+                                                      ws.numel(), C.c_void_p(stream.cuda_stream), self._o(options))
             check(rc, "ligdiff_ddpm_sample")
             return
         if properties is not None:
@@ -410,7 +434,7 @@ class ScoreNetworkEngine:
                                                       float(guidance_scale), float(temperature), _ptr(model.betas),
                                                       _ptr(model.alphas), _ptr(model.alphas_cumprod), int(n_steps),
                                                       int(seed), int(atom_offset), 1 if use_graph else 0, _ptr(ws),
-                                                      ws.numel(), _stream(), _opt(options))
+                                                      ws.numel(), _stream(), self._o(options))
             if run_on is not cur:
                 cur.wait_stream(run_on)
         check(rc, "ligdiff_ddpm_sample")
@@ -423,7 +447,7 @@ class ScoreNetworkEngine:
         self._check_sizes(graph)
         guided = 1 if (properties is not None and guidance_scale > 1.0) else 0
         nbytes = self.lib.ligdiff_ddpm_sample_workspace_bytes_opt(graph.n_atoms, graph.n_edges, graph.n_mols, guided,
-                                                                  n_steps, _opt(options))
+                                                                  n_steps, self._o(options))
         ws = self.workspace(nbytes)
         ts = torch.tensor([int(t) for t in timesteps], dtype=torch.int32, device=self.device)
         if properties is not None:
@@ -442,7 +466,7 @@ class ScoreNetworkEngine:
                 rc = self.lib.ligdiff_ddim_sample_opt(self.table, C.byref(graph.c), _ptr(x), _ptr(pos), _ptr(properties),
                                                       float(guidance_scale), _ptr(model.alphas_cumprod), _ptr(ts), n_steps,
                                                       _ptr(reject), 1 if use_graph else 0, _ptr(ws), ws.numel(), _stream(),
-                                                      _opt(options))
+                                                      self._o(options))
             if run_on is not cur:
                 cur.wait_stream(run_on)
         check(rc, "ligdiff_ddim_sample")

@@ -26,19 +26,26 @@ def cosine_beta_schedule(timesteps):
 
 class ResearchAccurateDiffusionModel(nn.Module):
     """Same constructor arguments, attributes, buffers and state_dict keys as
-    model1.py:574-665.  hidden_dim is fixed at 256, num_heads at 8, atom_feature_dim at
-    119 and three + three layers by the kernels' tiling; other values raise."""
+    model1.py:574-665.  hidden_dim is fixed at 256, num_heads at 8 and atom_feature_dim at 119 by the
+    kernels' tiling (other values raise); num_layers // 2 E(3) layers and as many attention layers as in
+    model1.py:627-634, for num_layers from 2 to 17 (6 is the reference's default, main.py:242 passes 8)."""
 
     def __init__(self, atom_feature_dim=119, edge_feature_dim=5, hidden_dim=256, num_layers=6,
                  num_heads=8, timesteps=1000, property_dim=15, max_atoms=100,
-                 sigma_min=0.002, sigma_max=80.0, sigma_data=0.5):
+                 sigma_min=0.002, sigma_max=80.0, sigma_data=0.5,
+                 use_equivariance=True, use_consistency=True, use_multi_objective=True):
         super().__init__()
+        # main.py:238-249 passes the three use_* switches (all True) to the model class it imports; the class of
+        # model1.py has no such parameters: every component is always built.  Accepted here as long as they ask for that.
+        if not (use_equivariance and use_consistency and use_multi_objective):
+            raise ValueError("the E(3) layers, the consistency module and the PILOT guidance are always built "
+                             "(model1.py:574-665 has no switch for them)")
         if hidden_dim != 256 or num_heads != 8 or atom_feature_dim != 119 or property_dim != 15:
             raise ValueError("the HIP kernels are built for hidden_dim=256, num_heads=8, "
                              "atom_feature_dim=119, property_dim=15")
-        if num_layers != 6:
-            raise ValueError("the HIP library runs three E(3) and three attention layers (num_layers=6, the "
-                             "reference's default, model1.py:580)")
+        if not 1 <= num_layers // 2 <= 8:
+            raise ValueError("the HIP library runs 1 to 8 E(3) layers and as many attention layers "
+                             "(num_layers // 2 of each, model1.py:627-634): num_layers must be 2..17")
         if max_atoms > 128:
             raise ValueError("max_atoms above 128 is not supported by the attention kernel")
         self.atom_feature_dim = atom_feature_dim
@@ -140,7 +147,7 @@ class ResearchAccurateDiffusionModel(nn.Module):
             eng = self.engine()
             ws, flags = eng.last_forward
             with torch.no_grad():
-                cons = eng.consistency(packed_graph_of(data), ws, flags, dropout)
+                cons = eng.consistency(packed_graph_of(data), ws, flags, dropout, options=getattr(self, "library_options", None))
         return atom_pred, pos_pred, prop_pred, cons
 
     def compute_loss(self, data, t, properties=None, loss_weights=None, draws=None):

@@ -52,6 +52,7 @@ extern "C" {
 #define LIGDIFF_E3_LAYERS 3
 #define LIGDIFF_DIT_LAYERS 3
 #define LIGDIFF_MAX_ATOMS 128
+#define LIGDIFF_MAX_LAYER_PAIRS 8   /* layers of each kind the weights table has slots for */
 
 enum ligdiff_status {
   LIGDIFF_OK = 0,
@@ -153,6 +154,9 @@ typedef struct ligdiff_options {
   int32_t mol_wave;          /* 0 / 1: molecule-per-wave attention layers (needs molecules of <= 32 atoms)   */
   int32_t edge_reduce;       /* 0 / 1: the fused edge path sums messages per destination itself              */
   int32_t cfg_two_pass;      /* 0 guided sampling as one doubled forward, 1 as two forwards                  */
+  int32_t layer_pairs;       /* 1..LIGDIFF_MAX_LAYER_PAIRS: E(3) layers = attention layers = num_layers // 2 */
+                             /* of the model whose weights table the call gets (model1.py:627-634); not set  */
+                             /* = 3 (num_layers = 6).  The table's slots of further layers are ignored.      */
 } ligdiff_options;
 
 /* Sets every field of *o to "not set". */
@@ -212,9 +216,9 @@ int ligdiff_forward(const float* const* weights, const ligdiff_graph* graph, con
 typedef struct ligdiff_dropout {
   uint64_t seed;            /* Philox key of this forward / backward pair                         */
   int64_t atom_offset;      /* global index of atom 0 of this call                                */
-  float p_attention[3];     /* per attention layer: probabilities, FFN hidden, FFN output         */
-  float p_ffn_hidden[3];
-  float p_ffn_out[3];
+  float p_attention[LIGDIFF_MAX_LAYER_PAIRS];   /* per attention layer: probabilities, FFN hidden, FFN output */
+  float p_ffn_hidden[LIGDIFF_MAX_LAYER_PAIRS];  /* (entries of layers the model does not have are ignored)    */
+  float p_ffn_out[LIGDIFF_MAX_LAYER_PAIRS];
   float p_consistency[2];   /* consistency module (model1.py:390, :401): Dropout inside the atom-type */
                             /* and the bond predictor; read by ligdiff_consistency_train only     */
 } ligdiff_dropout;
@@ -392,6 +396,9 @@ int ligdiff_set_chain_mode(int mode);
  * [n_atoms,3] (model1.py:752): the two inputs of the consistency module. */
 int ligdiff_forward_state_offsets(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int flags,
                                   size_t* hidden_offset, size_t* pos_offset);
+/* The same for a forward made under per-call options (the offsets depend on layer_pairs and gemm_mode). */
+int ligdiff_forward_state_offsets_opt(int64_t n_atoms, int64_t n_edges, int32_t n_mols, int flags,
+                                      size_t* hidden_offset, size_t* pos_offset, const ligdiff_options* options);
 
 /* MolDiff consistency module, train-mode fourth output of the model (model1.py:750-753, :453-561),
  * batched: the reference's Python double loop over atom pairs becomes row GEMMs over all ordered

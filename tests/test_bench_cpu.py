@@ -25,7 +25,7 @@ def test_traffic_table_comes_from_the_committed_pmc_summaries():
     assert source is not None and "profiles/" in source and "split" not in source
     # the kernels bench.py prices: fused attention-layer kernel and the aggregation kernel
     chain = bench.traffic_of(table, "dit_chain_kernel<0, true")
-    agg = bench.traffic_of(table, "k_aggregate(")
+    agg = bench.traffic_of(table, "k_aggregate")
     assert chain is not None and 100e6 < chain < 500e6          # 152 MB algorithmic per launch
     assert agg is not None and 96.4e6 <= agg < 130e6              # 96.4 MB algorithmic per launch
     assert bench.traffic_of(table, "no_such_kernel") is None

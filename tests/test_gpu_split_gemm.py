@@ -38,8 +38,18 @@ def test_switch_returns_previous_setting_and_sizes_the_workspace():
         off = lib.ligdiff_forward_workspace_bytes(290, 620, 10, 0)
         off_s = lib.ligdiff_ddpm_sample_workspace_bytes(290, 620, 10, 0, 50)
     # the split copies of the weights: 6 bytes per GEMM weight element and some slack
-    n_w = sum(lib.ligdiff_weight_numel(i) for i in range(lib.ligdiff_weight_count()))
+    # (the table also has slots for layers 3..7 of each kind, which the default six-layer model does not fill)
+    import re
+    n_w = 0
+    for i in range(lib.ligdiff_weight_count()):
+        m = re.match(r"(?:equivariant_layers|dit_layers)\.(\d+)\.", lib.ligdiff_weight_name(i).decode())
+        if m is None or int(m.group(1)) < 3:
+            n_w += lib.ligdiff_weight_numel(i)
     assert 4 * n_w < on - off < 12 * n_w and on_s - off_s == on - off
+    # a call that says it has four layers of each kind reserves more
+    o = _lib.Options(gemm_mode=1, layer_pairs=4)
+    import ctypes as C
+    assert lib.ligdiff_forward_workspace_bytes_opt(290, 620, 10, 0, C.byref(o)) > on
 
 
 @pytest.mark.parametrize("name,tkey,use_props,cfg", [
