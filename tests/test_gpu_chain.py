@@ -20,6 +20,7 @@ def _run(tmp_path, name, extra_env):
     env = dict(os.environ)
     env.pop("LIGDIFF_NO_CHAIN", None)
     env.pop("LIGDIFF_CHAIN", None)
+    env.pop("LIGDIFF_GEMM_SPLIT", None)     # the fused kernels are forms of the fp32 pipe
     env.update(extra_env)
     r = subprocess.run([sys.executable, os.path.join(HERE, "_chain_ab.py"), out], env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -60,6 +61,7 @@ def test_chain_mode_switch_in_process():
     model = ResearchAccurateDiffusionModel().cuda().eval()
     eng = model.engine()
     gen = ResearchValidatedGenerator(model)
+    gen.options = eng.options(gemm_mode=0)   # the fused kernels are forms of the fp32 pipe, whatever the process default
     prev = eng.set_chain_mode(0)
     try:
         assert prev == -1
@@ -118,7 +120,7 @@ def test_edge_reduce_form_matches_message_rows():
         pos = (torch.randn(g.n_atoms, 3, generator=gg) * 1.5).to(dev)
         outs = []
         for red in (0, 1):
-            o = eng.options(chain_mode=2, edge_reduce=red)
+            o = eng.options(gemm_mode=0, chain_mode=2, edge_reduce=red)
             with torch.no_grad():
                 a, p, _ = eng.forward(g, x, pos, None, None, want_props=False, t_index=t, options=o)
             outs.append((a.clone(), p.clone()))
@@ -129,7 +131,7 @@ def test_edge_reduce_form_matches_message_rows():
             assert float((u - v).abs().max()) <= 2e-5 * scale, (fc, float((u - v).abs().max()), scale)
         res = []
         for red in (0, 1):
-            gen.options = eng.options(chain_mode=2, edge_reduce=red)
+            gen.options = eng.options(gemm_mode=0, chain_mode=2, edge_reduce=red)
             xs, ps, _, _ = gen.sample_batch(sizes[:4], None, 1.0, 1.0, seed=11, connectivity="full" if fc else "template")
             res.append((xs.clone(), ps.clone()))
         gen.options = None
@@ -147,7 +149,7 @@ def test_plan_fixes_kernel_forms_for_halves_and_shards():
     model, gen = _model_gen(timesteps=6)
     eng = model.engine()
     sizes = [29] * 570                      # 16 530 atoms = 130 row blocks of 128: above half of 256 CUs; a half is 65
-    by_fill = eng.options(chain_mode=1)
+    by_fill = eng.options(gemm_mode=0, chain_mode=1)
     whole = eng.plan(sum(sizes), 62 * len(sizes), len(sizes), 29, by_fill)
     part = eng.plan(sum(sizes) // 2, 31 * len(sizes), len(sizes) // 2, 29, by_fill)
     assert whole.node_chain == 1 and whole.edge_chain == 1 and part.node_chain == 0   # the threshold is between them
