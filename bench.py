@@ -295,6 +295,8 @@ def leg_config3_train_step(ctx, steps=10, warmup=3, mols_per_rank=512):
                            "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_of(tr3, "gemm_dw_kernel<4>"),
                            "traffic_source": tr3_src,
+                           "timing_note": "the probed launch alone on the stream (ligdiff_backward_timed); inside a "
+                                          "training step it runs on the side stream under the input-gradient chain",
                            "traffic_note": "mean over the 12 launches of this kernel in a step (different shapes), "
                                            "rocprofv3 counters at this leg's shape",
                            "avg_launch_ms": ms}
@@ -430,7 +432,7 @@ def leg_config5_ragged_split_sweep(ctx, mols_per_rank=1024):
     def one_pass(i):
         res, flags = gen.sample_many(mine, None, 1.0, 1.0, use_ddim=False, seed=31 + i, atom_offset=sum(sizes[:lo]))
         return res, flags
-    dt, (res, flags) = ctx.timed(one_pass, 0, 1)
+    dt, (res, flags) = ctx.timed(one_pass, 1, 1)      # one untimed pass first (allocations, graph capture)
     rate = len(sizes) / dt
     finite = [bool(np.isfinite(r[0]).all() and np.isfinite(r[1]).all()) for r in res]
     prints = {fingerprint(r[0], r[1]) for r, ok in zip(res, finite) if ok}
@@ -517,6 +519,14 @@ def run_rank(args):
     pass_seconds = [round(b - a, 4) for a, b in zip(pass_ends, pass_ends[1:])]
     log(ctx, f"headline done: {dt:.2f} s; other GEMM mode ...")
     finite = bool(torch.isfinite(x).all() and torch.isfinite(pos).all())
+    # uniqueness of the last pass's molecules on this rank (atom-type multiset + pairwise distances to 0.1)
+    distinct = None
+    if finite:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from config5_sweep import fingerprint
+        xh, ph = x.detach().cpu().numpy(), pos.detach().cpu().numpy()
+        prints = {fingerprint(xh[m * ATOMS:(m + 1) * ATOMS], ph[m * ATOMS:(m + 1) * ATOMS]) for m in range(MOLS_PER_GPU)}
+        distinct = len(prints) / MOLS_PER_GPU
     # (every rank runs it, so the barriers inside stay matched; a failure here must not lose the headline)
     alt_error = None
     try:
@@ -624,7 +634,7 @@ def run_rank(args):
                                            "2 (the batch runs as two concurrent halves of 512 molecules; same bits as one call)")},
             "pass_seconds_rank0": pass_seconds,
             "attempted_molecules": world * MOLS_PER_GPU * args.steps,
-            "accepted_rank0": accepted, "finite": finite,
+            "accepted_rank0": accepted, "finite": finite, "distinct_last_pass_rank0": distinct,
             "roofline": roofline, "roofline_aggregation": roofline_agg,
             # the same K passes in the library's other GEMM mode (not the headline; see config.gemm_mode)
             "alt_gemm_mode": alt,

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void k_transpose_block(const float* __restrict
 // launch reads lives in a single-use buffer of the workspace pool or in the forward workspace, so the main chain
 // never overwrites it; join() at the end makes the caller's stream wait for the side stream.
 // LIGDIFF_DW_SIDE=0 keeps everything on the caller's stream (A/B switch).
+static thread_local bool g_bwd_one_stream = false;   // set by ligdiff_backward_timed: the probed launch runs alone
 struct SideStream {
   hipStream_t s = nullptr, s2 = nullptr;
   hipEvent_t* ev = nullptr;
@@ -97,7 +98,7 @@ struct SideStream {
   void init(hipStream_t main_stream) {
     s = s2 = main_stream;
     static const bool enabled = [] { const char* e = getenv("LIGDIFF_DW_SIDE"); return !(e != nullptr && e[0] == '0'); }();
-    if (!enabled) return;
+    if (!enabled || g_bwd_one_stream) return;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (main_stream != nullptr && (hipStreamIsCapturing(main_stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone))
       return;   // under capture: one stream
@@ -723,8 +724,10 @@ extern "C" int ligdiff_backward_timed(const float* const* w, float* const* gr, c
   for (int i = 0; i < reps && rc == LIGDIFF_OK; ++i) {
     p.seen = 0; p.hits = 0;
     g_bwd_probe = &p;
+    g_bwd_one_stream = true;   // the kernel's own duration: a training step overlaps it with the input-gradient chain
     rc = ligdiff_backward(w, gr, g, x, pos, properties, flags, d_atom, d_pos, d_prop, fwd_workspace, workspace,
                           workspace_bytes, stream);
+    g_bwd_one_stream = false;
     g_bwd_probe = nullptr;
     if (rc == LIGDIFF_OK && hipStreamSynchronize(s) != hipSuccess) rc = LIGDIFF_ERR_LAUNCH;
     if (rc == LIGDIFF_OK && p.hits != 1) rc = LIGDIFF_ERR_ARG;   // no such launch in this pass

@@ -291,8 +291,10 @@ int ligdiff_backward_opt(const float* const* weights, float* const* grads, const
  * returns in *mean_ms_host (host) the mean duration, from HIP events on `stream` net of an empty
  * event pair, of the wide_dw_index-th launch (in launch order within one pass) of the 256-column
  * weight-gradient kernel, and in dims3_host (host int64[3]) its shape {nout, kin, rows}:
- * dW[nout, kin] += dY[rows, nout]^T X[rows, kin], 2 nout kin rows flop.  Creates two events and
- * synchronises the stream; not for the training path. */
+ * dW[nout, kin] += dY[rows, nout]^T X[rows, kin], 2 nout kin rows flop.  These passes keep every launch
+ * on `stream` (a training step runs the weight-gradient launches on a side stream, overlapped with the
+ * input-gradient chain: there a launch's duration depends on what it shares the chip with).  Creates two
+ * events and synchronises the stream; not for the training path. */
 int ligdiff_backward_timed(const float* const* weights, float* const* grads, const ligdiff_graph* graph,
                            const float* x, const float* pos, const float* properties, int flags,
                            const float* d_atom, const float* d_pos, const float* d_prop,
