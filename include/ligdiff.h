@@ -71,6 +71,10 @@ const char* ligdiff_status_string(int status);
  * reads (model1.py:595-655), fp32, [out, in] row-major exactly as nn.Linear stores it.
  * ligdiff_weight_name(i) returns the state_dict key of slot i so a host binding can fill
  * the table by name; ligdiff_weight_numel(i) the element count it must have.
+ * The table has slots for LIGDIFF_MAX_LAYER_PAIRS E(3) layers ("equivariant_layers.<l>. ...") and as
+ * many attention layers ("dit_layers.<l>. ..."): model1.py:627-634 builds num_layers // 2 of each.
+ * A model with fewer leaves the slots of the layers it does not have NULL and passes its count in
+ * ligdiff_options.layer_pairs (calls without options assume 3, i.e. num_layers = 6).
  * ------------------------------------------------------------------------------- */
 int ligdiff_weight_count(void);
 const char* ligdiff_weight_name(int slot);
