@@ -33,6 +33,7 @@ class StepArgs(C.Structure):
                 ("seed", C.c_uint64), ("atom_offset", C.c_int64), ("n_atoms", C.c_int64)]
 
 
+ABI_VERSION = 2       # LIGDIFF_VERSION of include/ligdiff.h: struct layouts and table slots this binding mirrors
 MAX_LAYER_PAIRS = 8   # LIGDIFF_MAX_LAYER_PAIRS: E(3) / attention layers the weights table has slots for
 
 
@@ -201,8 +202,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.ligdiff_version() != 1:
-        raise LigdiffError("libligdiff.so version mismatch")
+    if lib.ligdiff_version() != ABI_VERSION:
+        raise LigdiffError(f"libligdiff.so has ABI version {lib.ligdiff_version()}, this binding expects {ABI_VERSION}: "
+                           "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
 

@@ -41,7 +41,9 @@
 extern "C" {
 #endif
 
-#define LIGDIFF_VERSION 1
+/* 2: ligdiff_options gained layer_pairs, ligdiff_dropout holds LIGDIFF_MAX_LAYER_PAIRS probabilities per site kind,
+ * the weights table has slots for LIGDIFF_MAX_LAYER_PAIRS layers of each kind */
+#define LIGDIFF_VERSION 2
 
 /* model constants the kernels are tiled for (model1.py:574-587 defaults) */
 #define LIGDIFF_HIDDEN 256
