@@ -115,6 +115,40 @@ __global__ __launch_bounds__(512, 2) void split_dbg(GemmCore g, SplitW sw, APtrP
     const bf16x8 A0 = __builtin_bit_cast(bf16x8, as[0]);
     const bf16x8 A1 = __builtin_bit_cast(bf16x8, as[1]);
     const bf16x8 A2 = __builtin_bit_cast(bf16x8, as[2]);
+    if (MODE & 32) {
+      // accumulators of a pair of column tiles take turns: consecutive MFMAs are independent
+      u32x4 bb[2][3];
+#pragma unroll
+      for (int cp = 0; cp < NTW; cp += 2) {
+        if (!(MODE & 8)) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+              bb[q][pl] = *reinterpret_cast<const u32x4*>(sB + pl * PLANE_B + (cp + q) * 32 * 16);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bb[q][pl] = b[0][pl];
+        }
+        const bf16x8 B00 = __builtin_bit_cast(bf16x8, bb[0][0]), B01 = __builtin_bit_cast(bf16x8, bb[0][1]), B02 = __builtin_bit_cast(bf16x8, bb[0][2]);
+        const bf16x8 B10 = __builtin_bit_cast(bf16x8, bb[1][0]), B11 = __builtin_bit_cast(bf16x8, bb[1][1]), B12 = __builtin_bit_cast(bf16x8, bb[1][2]);
+        acc[cp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B00, acc[cp], 0, 0, 0);
+        acc[cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B10, acc[cp + 1], 0, 0, 0);
+        acc[cp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B02, acc[cp], 0, 0, 0);
+        acc[cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B12, acc[cp + 1], 0, 0, 0);
+        acc[cp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B01, acc[cp], 0, 0, 0);
+        acc[cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B11, acc[cp + 1], 0, 0, 0);
+        acc[cp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B00, acc[cp], 0, 0, 0);
+        acc[cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B10, acc[cp + 1], 0, 0, 0);
+        acc[cp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B01, acc[cp], 0, 0, 0);
+        acc[cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B11, acc[cp + 1], 0, 0, 0);
+        acc[cp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B00, acc[cp], 0, 0, 0);
+        acc[cp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B10, acc[cp + 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int ct = 0; ct < NTW; ++ct) {
       const int bi = (MODE & 8) ? 0 : (ct & 1);
@@ -137,6 +171,7 @@ __global__ __launch_bounds__(512, 2) void split_dbg(GemmCore g, SplitW sw, APtrP
       acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc[ct], 0, 0, 0);
       acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc[ct], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
   }
   HalfMailbox mb{smem4 + NSA * A_FL + 2 * B_FL, wave, lane};
@@ -200,6 +235,9 @@ int main() {
     RUN(7, en, "no DMA, no barrier, no split")
     RUN(15, en, "MFMA only")
     RUN(8, en, "no LDS fragment reads (DMA, barrier, split stay)")
+    RUN(32 | 15, en, "MFMA only, two accumulators taking turns")
+    RUN(32, en, "two accumulators taking turns, no epilogue")
+    RUN(32, e, "two accumulators taking turns, bias + store")
     RUN(16, en, "W-piece DMAs behind the MFMA groups, no epilogue")
     RUN(16, e, "W-piece DMAs behind the MFMA groups, bias + store")
   }
