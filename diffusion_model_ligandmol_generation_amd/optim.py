@@ -81,7 +81,8 @@ class FusedAdamW(torch.optim.AdamW):
             stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             for step0, entries in sorted(entries_by_step.items()):
                 step = step0 + 1.0
-                key = (flat.data_ptr(), tuple((p.data_ptr(), m.data_ptr(), off) for p, m, _, off in entries))
+                # (the rows hold parameter / moment addresses and offsets INTO the flat buffer, not its address)
+                key = tuple((p.data_ptr(), m.data_ptr(), off) for p, m, _, off in entries)
                 tab, chunk_t, chunk_s = self._table(key, entries, dev)
                 check(lib.ligdiff_adamw_step(tab.data_ptr(), chunk_t.data_ptr(), chunk_s.data_ptr(), chunk_t.numel(),
                                              flat.data_ptr(), flat.numel(), float(group["lr"]), float(beta1), float(beta2),
