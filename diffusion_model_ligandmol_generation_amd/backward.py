@@ -108,6 +108,9 @@ class ScoreNetworkFunction(torch.autograd.Function):
             elif name.startswith("property_output."):
                 used = d_prop is not None
             out.append(gten if used else None)
+        # (names whose slice holds a gradient: the fused optimiser step takes its norm over the whole buffer, so it
+        # checks that exactly these reached a parameter's .grad)
+        eng.last_flat["live"] = {n for n, gten in zip(pnames, out) if gten is not None}
         return (None, *out)
 
     @staticmethod

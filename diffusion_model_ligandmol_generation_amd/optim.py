@@ -52,9 +52,11 @@ class FusedAdamW(torch.optim.AdamW):
             if names is None:
                 names = self._names = {id(p): n for n, p in model.named_parameters()}
             base = flat.data_ptr()
+            seen = set()
             for p in group["params"]:
                 if p.grad is None:
                     continue
+                seen.add(names.get(id(p)))
                 off = offsets.get(names.get(id(p)))
                 if (off is None or p.grad.data_ptr() != base + 4 * off or p.dtype != torch.float32 or not p.is_contiguous()
                         or p.grad.dtype != torch.float32):
@@ -66,6 +68,10 @@ class FusedAdamW(torch.optim.AdamW):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 entries_by_step.setdefault(float(st["step"]), []).append((p, st["exp_avg"], st["exp_avg_sq"], off))
+            # the norm is taken over the whole buffer: every slice that holds a gradient must belong to a parameter of
+            # this optimiser (a frozen parameter's slice would enter the norm but not torch's clip_grad_norm_)
+            if ok and seen != info.get("live", seen):
+                ok = False
         if not ok or not entries_by_step:
             self.last_path = "torch"
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)

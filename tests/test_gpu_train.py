@@ -360,3 +360,10 @@ def test_fused_clip_and_adamw_matches_torch():
     assert {float(s["step"]) for s in tr.optimizer.state.values() if s} == {2.0, 3.0}      # 2: the PILOT parameters
     # a checkpoint of the fused optimiser loads into a stock AdamW
     torch.optim.AdamW(m.parameters(), lr=1e-3).load_state_dict(tr.optimizer.state_dict())
+    # a frozen parameter's slice of the flat buffer would enter the fused norm but not clip_grad_norm_'s: stock path
+    pa["atom_output.3.bias"].requires_grad_(False)
+    tr.optimizer.zero_grad()
+    tr._compute_research_exact_loss(batch, training=True, draws=draws)["total_loss"].backward()
+    assert pa["atom_output.3.bias"].grad is None
+    tr.optimizer.clip_and_step(m, max_norm=1.0)
+    assert tr.optimizer.last_path == "torch"
