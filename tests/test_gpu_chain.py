@@ -140,6 +140,39 @@ def test_edge_reduce_form_matches_message_rows():
             assert float((u - v).abs().max()) <= 2e-4 * max(1.0, float(u.abs().max()))
 
 
+def test_edge_reduce_form_with_molecules_that_have_no_edge():
+    """A caller-supplied graph in which some molecules have no edge at all (one-atom molecules, data_utils.py:889-895
+    without the self loop) between fully connected ones: such a molecule owns no slab and its atom sums nothing."""
+    import torch
+    from diffusion_model_ligandmol_generation_amd.engine import PackedGraph
+    model, _ = _model_gen(128, timesteps=8)
+    eng = model.engine()
+    dev = torch.device("cuda")
+    sizes = [65, 1, 100, 1, 1, 70]
+    ei, batch, off = [], [], 0
+    for m, n in enumerate(sizes):
+        ii, jj = torch.meshgrid(torch.arange(n), torch.arange(n), indexing="ij")
+        ei.append(torch.stack([ii[ii != jj], jj[ii != jj]]) + off)
+        batch.append(torch.full((n,), m, dtype=torch.long))
+        off += n
+    g = PackedGraph(torch.cat(ei, 1).to(dev), torch.cat(batch).to(dev))
+    assert g.n_edges >= 8 * g.n_atoms
+    gg = torch.Generator().manual_seed(6)
+    x = torch.randn(g.n_atoms, 119, generator=gg).to(dev)
+    pos = (torch.randn(g.n_atoms, 3, generator=gg) * 1.5).to(dev)
+    t = torch.tensor([5], dtype=torch.int32, device=dev)
+    outs = []
+    for o in (eng.options(gemm_mode=0, chain_mode=2, edge_reduce=0), eng.options(gemm_mode=0, chain_mode=2, edge_reduce=1),
+              eng.options(gemm_mode=0, chain_mode=0)):
+        with torch.no_grad():
+            a, p, _ = eng.forward(g, x, pos, None, None, want_props=False, t_index=t, options=o)
+        outs.append((a.clone(), p.clone()))
+    for k in (1, 2):
+        for u, v in zip(outs[0], outs[k]):
+            assert torch.isfinite(u).all() and torch.isfinite(v).all()
+            assert float((u - v).abs().max()) <= 2e-5 * max(1.0, float(u.abs().max())), k
+
+
 def test_plan_fixes_kernel_forms_for_halves_and_shards():
     """By-fill mode (no LIGDIFF_CHAIN override) at a size just above the fill threshold of the fused kernels, where a
     half or a shard on its own would fall below it: the generator plans ONCE on the whole batch (ligdiff_plan) and
