@@ -22,6 +22,10 @@ struct EdgeChainArgs {
   const int32_t* slab_e0;    // REDUCE form: first edge / edge count (<= 32) of every slab; n_slabs entries, the ones
   const int32_t* slab_cnt;   //   past the last molecule's slabs hold (0, 0)
   int n_slabs;               // REDUCE form: table length = grid size * 4
+  // GEOM form: the edge geometry and the radial MLP (model1.py:88-93) run inside the kernel; rbf / rel are not read
+  const float* pos;          // [N,3] coordinates this layer sees
+  const float* rw0; const float* rb0;   // radial_basis.0: weight [32] (Linear(1, 32)), bias [32]
+  const float* rW2; const float* rb2;   // radial_basis.2: weight [32,32], bias [32]
 };
 
 enum { NODE_TAIL_NONE = 0, NODE_TAIL_PROJ = 1, NODE_TAIL_QKV = 2 };

@@ -25,12 +25,18 @@
 // slab_e0 / slab_cnt, built by k_slab_scan / k_slab_fill; a molecule's last slab may be short), so how an atom's
 // messages are grouped into partial sums - and with it every bit of the result - depends on the molecule alone, not
 // on what precedes it in the batch.
-template <bool DBG = false, int ABL = 0, bool REDUCE = false>   // ABL: timing ablations (developer switch; results are wrong when non-zero)
+//
+// GEOM: the layer's edge geometry and radial MLP (model1.py:88-93: rel = pos[dst] - pos[src], d = ||rel + 1e-8||,
+// rbf = W2 SiLU(w0 d + b0) + b2) run in the prologue instead of a launch of their own: a lane builds the 16 hidden
+// units of its half of the edge's row in registers (B layout), the 32 x 32 weight sits in LDS as the first 32 rows
+// of a TALL tile, and the accumulator tile of that product IS the rbf slab the first edge linear multiplies.
+template <bool DBG = false, int ABL = 0, bool REDUCE = false, bool GEOM = false>   // ABL: timing ablations (developer switch; results are wrong when non-zero)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void edge_chain_kernel(EdgeChainArgs p) {
-  __shared__ __attribute__((aligned(1024))) float smem[4 * CH_TILE_FL + 1024];
+  __shared__ __attribute__((aligned(1024))) float smem[4 * CH_TILE_FL + 1024 + (GEOM ? 1024 : 0)];
   float* const ring = smem + CH_TILE_FL;      // smem[0 .. 8192): the Wc tile
   float* const vec = smem + 4 * CH_TILE_FL;   // b2 | gamma | beta | bc1 | wc2
+  float* const geo = vec + 1024;              // GEOM: radial_basis.2 weight, rows 0..31 of a TALL tile (4 KiB)
   const int tid = threadIdx.x;
   ChainLane cl;
   cl.init(smem, tid);
@@ -46,6 +52,12 @@ void edge_chain_kernel(EdgeChainArgs p) {
   for (int n = 0; n < 8; ++n) cl.dma_tall(p.W2, 256, 0, ring, n);
 #pragma unroll
   for (int n = 0; n < 8; ++n) cl.dma_tall(p.W2, 256, 32, ring + CH_TILE_FL, n);
+  if constexpr (GEOM) {
+    if (cl.wave == 0) {   // pieces 0..3 of a TALL tile = rows 0..31
+#pragma unroll
+      for (int n = 0; n < 4; ++n) cl.dma_tall(p.rW2, 32, 0, geo, n);
+    }
+  }
   // prologue loads: the edge's end points first (the P gathers depend on them), everything else behind them, the LDS
   // write of the small vectors last, so that the wave waits for memory twice (indices, then the rest) and not four times
   int e_raw, e;
@@ -66,9 +78,25 @@ void edge_chain_kernel(EdgeChainArgs p) {
                    : tid < 192 ? p.beta + (tid - 128) * 4 : tid < 224 ? p.bc1 + (tid - 192) * 4 : p.wc2 + (tid - 224) * 4;
   const f32x4 sv = *reinterpret_cast<const f32x4*>(svp);
   f32x4 rb[4];
+  f32x4 relv;
+  if constexpr (GEOM) {
+    const float* ps = p.pos + (size_t)i_src * 3;
+    const float* pd = p.pos + (size_t)i_dst * 3;
+    const float rx = pd[0] - ps[0], ry = pd[1] - ps[1], rz = pd[2] - ps[2];
+    const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
+    const float dist = sqrtf(ex * ex + ey * ey + ez * ez);
+    relv = f32x4{rx, ry, rz, 0.f};
 #pragma unroll
-  for (int m = 0; m < 4; ++m) rb[m] = *reinterpret_cast<const f32x4*>(p.rbf + (size_t)e * 32 + 8 * m + 4 * h);
-  const f32x4 relv = *reinterpret_cast<const f32x4*>(p.rel + (size_t)e * 4);
+    for (int m = 0; m < 4; ++m) {   // hidden units k = 8m + 4h + (0..3) of this lane's half of the row
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.rw0 + 8 * m + 4 * h);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.rb0 + 8 * m + 4 * h);
+      rb[m] = f32x4{silu(dist * w0[0] + b0[0]), silu(dist * w0[1] + b0[1]), silu(dist * w0[2] + b0[2]), silu(dist * w0[3] + b0[3])};
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rb[m] = *reinterpret_cast<const f32x4*>(p.rbf + (size_t)e * 32 + 8 * m + 4 * h);
+    relv = *reinterpret_cast<const f32x4*>(p.rel + (size_t)e * 4);
+  }
   const float bc2 = p.bc2[0];
   const float* pa = p.P + (size_t)i_src * 512 + 4 * h;
   const float* pb = p.P + (size_t)i_dst * 512 + 256 + 4 * h;
@@ -78,8 +106,25 @@ void edge_chain_kernel(EdgeChainArgs p) {
     ga[g] = *reinterpret_cast<const f32x4*>(pa + 8 * g);
     gb[g] = *reinterpret_cast<const f32x4*>(pb + 8 * g);
   }
+  f32x4 rbias[4];
+  if constexpr (GEOM) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) rbias[g] = *reinterpret_cast<const f32x4*>(p.rb2 + 8 * g + 4 * h);
+  }
   *reinterpret_cast<f32x4*>(vec + tid * 4) = sv;
   __syncthreads();
+  if constexpr (GEOM) {   // rbf^T = W2 hidden^T + b2: four MFMA groups over the 32 x 32 weight
+    f32x16 ur;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { ur[4 * g] = rbias[g][0]; ur[4 * g + 1] = rbias[g][1]; ur[4 * g + 2] = rbias[g][2]; ur[4 * g + 3] = rbias[g][3]; }
+    unsigned ag[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ag[g] = cl.a_tall[g] + (4 * CH_TILE_FL + 1024) * 4;
+    chain_groups<4>([&](auto J) { return lds_read128<0>(ag[decltype(J)::value]); },
+                    [&](auto J) { return rb[decltype(J)::value]; }, [&](auto) -> f32x16& { return ur; });
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rb[m] = f32x4{ur[4 * m], ur[4 * m + 1], ur[4 * m + 2], ur[4 * m + 3]};
+  }
   stamp(1);
   f32x16 msg[8];
 #pragma unroll

@@ -565,11 +565,16 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
       PE();
     }
     if (E > 0) {
-      PB("e3_%d.edge_geom", l);
-      hipLaunchKernelGGL(k_edge_geom, dim3(ceil_div(E, 128)), dim3(256), 0, s, pos_l, g->src, g->dst,
-                         w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB0_B)], w[W_E3(l, E3_RB2_W)], w[W_E3(l, E3_RB2_B)],
-                         F(L.rel[l]), F(L.rbf[l]), S(L.dist[l]), S(L.r1pre[l]), E);
-      PE();
+      // the fused edge kernel computes the geometry and the radial MLP itself (LIGDIFF_EDGE_GEOM=0: A/B switch)
+      static const bool geom_fused = [] { const char* e = getenv("LIGDIFF_EDGE_GEOM"); return !(e != nullptr && e[0] == '0'); }();
+      const bool edge_geom_inside = edge_chain && geom_fused;
+      if (!edge_geom_inside) {
+        PB("e3_%d.edge_geom", l);
+        hipLaunchKernelGGL(k_edge_geom, dim3(ceil_div(E, 128)), dim3(256), 0, s, pos_l, g->src, g->dst,
+                           w[W_E3(l, E3_RB0_W)], w[W_E3(l, E3_RB0_B)], w[W_E3(l, E3_RB2_W)], w[W_E3(l, E3_RB2_B)],
+                           F(L.rel[l]), F(L.rbf[l]), S(L.dist[l]), S(L.r1pre[l]), E);
+        PE();
+      }
       if (edge_chain) {
         EdgeChainArgs ea;
         memset(&ea, 0, sizeof ea);
@@ -579,6 +584,10 @@ int run_forward(const float* const* w, const ligdiff_graph* g, const float* x, c
         ea.Wc1 = w[W_E3(l, E3_CN0_W)]; ea.bc1 = w[W_E3(l, E3_CN0_B)]; ea.wc2 = w[W_E3(l, E3_CN2_W)]; ea.bc2 = w[W_E3(l, E3_CN2_B)];
         ea.msg = F(L.msg[l]); ea.wrel = F(L.wrel[l]);
         if (edge_reduce) { ea.part = F(L.msg[l]); ea.slab_e0 = slab_e0; ea.slab_cnt = slab_cnt; ea.n_slabs = (int)L.n_slab_cap; }
+        if (edge_geom_inside) {
+          ea.pos = pos_l; ea.rw0 = w[W_E3(l, E3_RB0_W)]; ea.rb0 = w[W_E3(l, E3_RB0_B)];
+          ea.rW2 = w[W_E3(l, E3_RB2_W)]; ea.rb2 = w[W_E3(l, E3_RB2_B)];
+        }
         PB("e3_%d.edge_chain", l);
         launch_edge_chain(ea, s);
         PE();
