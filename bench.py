@@ -377,10 +377,10 @@ def leg_config4_fc_sampling(ctx, mols_per_rank=48):
         try:     # edge pre-activation, second edge linear + LN, coordinate gate (+ per-destination sums)
             eng.time_launch("e3_1.edge_chain", g2, xr, pr, t_index, reps=2, options=plan)
             ms = eng.time_launch("e3_1.edge_chain", g2, xr, pr, t_index, reps=5, options=plan)
-            flops = 2.0 * E * (32 * 256 + 256 * 256 + 256 * 128)
-            name = (f"edge_chain_kernel (e3_*.edge_chain, E={E}: K=32 + 256x256 + 256x128 per edge"
+            flops = 2.0 * E * (32 * 32 + 32 * 256 + 256 * 256 + 256 * 128)
+            name = (f"edge_chain_kernel (e3_*.edge_chain, E={E}: radial 32x32 + K=32 + 256x256 + 256x128 per edge"
                     + (", per-destination message sums inside the kernel)" if plan.edge_reduce else ")"))
-            needle = ("edge_chain_kernel<false, 0, true>",) if plan.edge_reduce else ("edge_chain_kernel<false, 0>",)
+            needle = ("edge_chain_kernel<false, 0, true",) if plan.edge_reduce else ("edge_chain_kernel<false, 0, false",)
         except Exception:   # noqa: BLE001  (separate launches: the second edge-MLP GEMM is the largest)
             eng.time_launch("e3_1.edge_mlp2", g2, xr, pr, t_index, reps=2, options=plan)
             ms = eng.time_launch("e3_1.edge_mlp2", g2, xr, pr, t_index, reps=5, options=plan)
