@@ -47,6 +47,9 @@ class ResearchValidatedGenerator:
         # the other's matrix time (2.40 -> 2.34 ms per reverse step at 1024 x 29 atoms; 600 molecules 2.33 -> 2.20,
         # neutral from 700 to 900, and a loss below 550, where a half no longer fills half of the chip).  None switches it off.
         self.concurrent_atoms = 17000
+        # fully connected large ligands have few atoms and many edges: there the halves pay from about 400 000 edges
+        # (48 ligands of 65-128 atoms: 3.77 -> 3.65 ms per reverse step; 24 ligands, 250 000 edges: 2.19 -> 2.30)
+        self.concurrent_edges = 400000
         self._half_streams = []
         # Per-call library options (an engine Options struct, or None for the library's defaults).  Whatever it
         # leaves open is resolved ONCE per packed batch from the whole batch's sizes (engine.plan_graph) and the
@@ -237,7 +240,8 @@ class ResearchValidatedGenerator:
             pos = (noise("pos0", T, (N, 3)) * temperature).contiguous()
         rejected = torch.zeros(B, dtype=torch.int32, device=dev)
         halves = (not zero_cond and not use_ddim and noise is None and trace is None and use_graph and self.concurrent_atoms is not None
-                  and N >= self.concurrent_atoms and B >= 8 and connectivity in ("template", "full"))
+                  and (N >= self.concurrent_atoms or graph.n_edges >= self.concurrent_edges) and B >= 8
+                  and connectivity in ("template", "full"))
         # kernel forms of this batch, fixed on the whole batch's sizes whichever way it is then cut
         opts = eng.plan_graph(graph, options if options is not None else self.options)
         if halves:   # the hint only steers choices between bit-identical GEMM tile forms once the plan is fixed
