@@ -85,3 +85,28 @@ def test_constructor_rejects_shapes_the_kernels_are_not_built_for():
     # num_layers // 2 layers of each kind, as model1.py:627-634 builds them (main.py:242 asks for 8)
     m = ResearchAccurateDiffusionModel(num_layers=8)
     assert len(m.equivariant_layers) == 4 and len(m.dit_layers) == 4
+
+
+def test_layer_count_option_sizes_workspaces_and_is_validated():
+    """ligdiff_options.layer_pairs (E(3) layers = attention layers of the model behind the weights table): host-side
+    effects only - workspace sizes follow it, ligdiff_plan hands it through, values beyond the table's slots are refused."""
+    import ctypes as C
+    from diffusion_model_ligandmol_generation_amd import _lib
+    lib = _lib.load()
+    save = _lib.FWD_SAVE_FOR_BACKWARD
+    sizes = {}
+    for lp in (-1, 1, 3, 4, 8):
+        o = _lib.Options(layer_pairs=lp)
+        sizes[lp] = (lib.ligdiff_forward_workspace_bytes_opt(2900, 6200, 100, save, C.byref(o)),
+                     lib.ligdiff_backward_workspace_bytes_opt(2900, 6200, 100, C.byref(o)),
+                     lib.ligdiff_ddpm_sample_workspace_bytes_opt(2900, 6200, 100, 0, 50, C.byref(o)))
+    assert sizes[-1] == sizes[3]                                          # not set = the reference's default of six layers
+    assert sizes[-1][0] == lib.ligdiff_forward_workspace_bytes(2900, 6200, 100, save)
+    for k in range(3):
+        assert sizes[1][k] < sizes[3][k] < sizes[4][k] < sizes[8][k]
+    bad = _lib.Options(layer_pairs=_lib.MAX_LAYER_PAIRS + 1)
+    assert lib.ligdiff_forward_workspace_bytes_opt(2900, 6200, 100, 0, C.byref(bad)) == 0
+    out = _lib.Options()
+    assert lib.ligdiff_plan(2900, 6200, 100, 29, C.byref(bad), C.byref(out)) != 0
+    assert lib.ligdiff_plan(2900, 6200, 100, 29, C.byref(_lib.Options(layer_pairs=4, gemm_mode=1)), C.byref(out)) == 0
+    assert out.layer_pairs == 4 and out.gemm_mode == 1 and out.edge_chain in (0, 1)
