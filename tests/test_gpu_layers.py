@@ -188,6 +188,17 @@ def test_sampling_loops_with_other_layer_counts(num_layers, chain):
     xc, pc, _, _ = gen.sample_batch(sizes, None, 1.0, 1.0, seed=11)
     torch.testing.assert_close(xc, xa, rtol=1e-3, atol=1e-3 * float(xa.abs().max()))
     torch.testing.assert_close(pc, pa, rtol=1e-3, atol=1e-3 * float(pa.abs().max()))
+    # molecule-per-wave form of the attention-layer kernel (ligands of at most 32 atoms that fill their slabs)
+    full = [29] * 12
+    assert m.engine().plan(29 * 12, 62 * 12, 12, 29, m.engine().options(gemm_mode=0, chain_mode=2)).mol_wave == 1
+    outs = []
+    for cm in (2, 0):
+        gen.options = m.engine().options(gemm_mode=0, chain_mode=cm)
+        outs.append(gen.sample_batch(full, None, 1.0, 1.0, seed=13)[:2])
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.isfinite(u).all() and not torch.equal(u, v)
+        torch.testing.assert_close(u, v, rtol=1e-3, atol=1e-3 * float(v.abs().max()))
+    gen.options = m.engine().options(chain_mode=0 if chain else 2)
     props = torch.rand(len(sizes), 15, generator=torch.Generator().manual_seed(3))
     xg, pg, _, _ = gen.sample_batch(sizes, props, 2.0, 0.9, seed=5)                       # guided, one doubled forward
     xd, pd, _, _ = gen.sample_batch(sizes, None, 1.0, 1.0, use_ddim=True, num_steps=5, seed=5)
